@@ -1,0 +1,335 @@
+#include "scheduler.hpp"
+
+#include <algorithm>
+#include <stdexcept>
+
+namespace lc {
+
+Scheduler::Scheduler(std::shared_ptr<KVManager> kv, SchedulerConfig cfg)
+    : kv_(std::move(kv)), cfg_(cfg) {}
+
+int Scheduler::add_request(RequestKind kind, std::vector<int32_t> prompt, int n_chains,
+                           SamplingParams p) {
+  if (prompt.empty()) throw std::invalid_argument("Scheduler::add_request: empty prompt");
+  if (n_chains < 1) n_chains = 1;
+  if (kind != RequestKind::Generate) {
+    n_chains = 1;
+    p.max_new_tokens = 0;
+  }
+  Group g;
+  g.id = next_id_++;
+  g.kind = kind;
+  g.prompt = std::move(prompt);
+  g.p = std::move(p);
+  g.n = n_chains;
+  const int bs = kv_->block_size();
+  const int P = static_cast<int>(g.prompt.size());
+  // Worst case: the prompt's blocks once, plus per chain a private copy of the
+  // partially filled tail block and the blocks its generated tokens spill into.
+  int per_chain = ((P % bs) + g.p.max_new_tokens + bs - 1) / bs;
+  g.budget_blocks = P / bs + n_chains * std::max(per_chain, (P % bs) ? 1 : 0);
+  if (g.budget_blocks > kv_->stats().blocks_total || n_chains > cfg_.max_batch_seqs)
+    throw std::invalid_argument("Scheduler::add_request: request can never fit in the KV pool");
+  int id = g.id;
+  groups_.emplace(id, std::move(g));
+  waiting_.push_back(id);
+  return id;
+}
+
+const SamplingParams& Scheduler::params_of(int request_id) const { return groups_.at(request_id).p; }
+RequestKind Scheduler::kind_of(int request_id) const { return groups_.at(request_id).kind; }
+
+int Scheduler::num_running() const {
+  int n = 0;
+  for (int gid : running_) {
+    const Group& g = groups_.at(gid);
+    for (const auto& c : g.chains) n += c.done ? 0 : 1;
+  }
+  return n;
+}
+
+bool Scheduler::has_work() const {
+  return !waiting_.empty() || !prefilling_.empty() || !running_.empty();
+}
+
+bool Scheduler::try_admit(Group& g) {
+  // Chains already promised to admitted groups.
+  int promised = 0;
+  for (int gid : prefilling_) promised += groups_.at(gid).n;
+  for (int gid : running_) promised += groups_.at(gid).n;
+  if (promised + g.n > cfg_.max_batch_seqs) return false;
+  if (budget_used_ + g.budget_blocks > kv_->stats().blocks_total) return false;
+  int cached = 0;
+  int seq = kv_->create_sequence(g.prompt.data(), static_cast<int>(g.prompt.size()), &cached);
+  if (seq < 0) return false;
+  g.cached = cached;
+  g.computed = cached;
+  g.admitted = true;
+  g.chains.assign(1, Chain{});
+  g.chains[0].seq = seq;
+  budget_used_ += g.budget_blocks;
+  return true;
+}
+
+namespace {
+// Writes ragged block tables as a padded [B, max_blocks] matrix.
+void pack_block_tables(StepPlan& plan, const KVManager& kv) {
+  const int B = static_cast<int>(plan.seq_ids.size());
+  int mb = 1;
+  for (int s : plan.seq_ids) mb = std::max(mb, static_cast<int>(kv.block_table(s).size()));
+  plan.max_blocks = mb;
+  plan.block_tables.assign(static_cast<size_t>(B) * mb, -1);
+  for (int b = 0; b < B; ++b) {
+    const auto& bt = kv.block_table(plan.seq_ids[b]);
+    std::copy(bt.begin(), bt.end(), plan.block_tables.begin() + static_cast<size_t>(b) * mb);
+  }
+}
+}  // namespace
+
+StepPlan Scheduler::schedule() {
+  StepPlan plan;
+  while (!waiting_.empty()) {
+    Group& g = groups_.at(waiting_.front());
+    if (!try_admit(g)) break;
+    prefilling_.push_back(g.id);
+    waiting_.pop_front();
+  }
+  const int bs = kv_->block_size();
+
+  if (!prefilling_.empty()) {
+    plan.kind = StepPlan::Prefill;
+    int budget = cfg_.max_prefill_tokens;
+    plan.cu_q.push_back(0);
+    for (int gid : prefilling_) {
+      if (budget <= 0) break;
+      Group& g = groups_.at(gid);
+      const int P = static_cast<int>(g.prompt.size());
+      const int take = std::min(P - g.computed, budget);
+      if (take <= 0) continue;
+      const int seq = g.chains[0].seq;
+      const auto& bt = kv_->block_table(seq);
+      const int row0 = static_cast<int>(plan.token_ids.size());
+      for (int i = 0; i < take; ++i) {
+        const int pos = g.computed + i;
+        plan.token_ids.push_back(g.prompt[pos]);
+        plan.positions.push_back(pos);
+        plan.slot_mapping.push_back(bt[pos / bs] * bs + pos % bs);
+      }
+      plan.seq_ids.push_back(seq);
+      plan.request_ids.push_back(gid);
+      plan.context_lens.push_back(g.computed + take);
+      plan.cu_q.push_back(row0 + take);
+      if (g.computed + take == P) {
+        plan.last_rows.push_back(row0 + take - 1);
+        plan.last_row_seq.push_back(static_cast<int>(plan.seq_ids.size()) - 1);
+      }
+      budget -= take;
+    }
+    pack_block_tables(plan, *kv_);
+    return plan;
+  }
+
+  if (!running_.empty()) {
+    plan.kind = StepPlan::Decode;
+    for (int gid : running_) {
+      Group& g = groups_.at(gid);
+      const int first = static_cast<int>(plan.seq_ids.size());
+      int live = 0;
+      int min_pos = 1 << 30;
+      for (size_t k = 0; k < g.chains.size(); ++k) {
+        Chain& c = g.chains[k];
+        if (c.done) continue;
+        if (!kv_->reserve(c.seq, 1))
+          throw std::runtime_error("Scheduler: KV pool exhausted despite admission budget");
+        const int pos = kv_->num_tokens(c.seq);
+        const auto& bt = kv_->block_table(c.seq);
+        plan.seq_ids.push_back(c.seq);
+        plan.request_ids.push_back(gid);
+        plan.token_ids.push_back(c.last_token);
+        plan.positions.push_back(pos);
+        plan.slot_mapping.push_back(bt[pos / bs] * bs + pos % bs);
+        plan.context_lens.push_back(pos + 1);
+        plan.step_index.push_back(static_cast<int32_t>(c.out.size()));
+        plan.seeds.push_back(g.p.seed + k);
+        min_pos = std::min(min_pos, pos);
+        ++live;
+      }
+      if (live == 0) continue;
+      int shared = 0;
+      if (live > 1) {
+        // Longest common prefix of the live chains' block tables, limited to blocks
+        // that are complete and no longer written by anyone.
+        const int limit = min_pos / bs;
+        const auto& bt0 = kv_->block_table(plan.seq_ids[first]);
+        shared = limit;
+        for (int r = first + 1; r < first + live; ++r) {
+          const auto& bt = kv_->block_table(plan.seq_ids[r]);
+          int m = 0;
+          while (m < shared && bt[m] == bt0[m]) ++m;
+          shared = m;
+        }
+      }
+      plan.group_first.push_back(first);
+      plan.group_count.push_back(live);
+      plan.group_shared_blocks.push_back(shared);
+    }
+    auto copies = kv_->take_pending_copies();
+    for (auto& c : copies) {
+      plan.copy_src.push_back(c.first);
+      plan.copy_dst.push_back(c.second);
+    }
+    pack_block_tables(plan, *kv_);
+    return plan;
+  }
+  return plan;
+}
+
+std::vector<Scheduler::SampleSlot> Scheduler::prefill_sample_layout(const StepPlan& plan) const {
+  std::vector<SampleSlot> out;
+  for (size_t j = 0; j < plan.last_rows.size(); ++j) {
+    const Group& g = groups_.at(plan.request_ids[plan.last_row_seq[j]]);
+    if (g.kind != RequestKind::Generate || g.p.max_new_tokens <= 0) continue;
+    for (int k = 0; k < g.n; ++k)
+      out.push_back({static_cast<int>(j), k, g.p.seed + static_cast<uint64_t>(k), g.p.temperature,
+                     g.p.top_p, g.p.top_k});
+  }
+  return out;
+}
+
+bool Scheduler::is_stop(const Group& g, int32_t tok, FinishReason* why) const {
+  if (!g.p.ignore_eos && g.p.eos_id >= 0 && tok == g.p.eos_id) {
+    *why = FinishReason::Eos;
+    return true;
+  }
+  for (int32_t s : g.p.stop_ids)
+    if (tok == s) {
+      *why = FinishReason::Stop;
+      return true;
+    }
+  return false;
+}
+
+void Scheduler::finish_chain(Group& g, Chain& c, FinishReason r) {
+  (void)g;
+  c.done = true;
+  c.reason = r;
+  if (c.seq >= 0) {
+    kv_->free_sequence(c.seq);
+    c.seq = -1;
+  }
+}
+
+void Scheduler::maybe_retire(int gid) {
+  Group& g = groups_.at(gid);
+  for (const auto& c : g.chains)
+    if (!c.done) return;
+  FinishedRequest f;
+  f.request_id = gid;
+  f.kind = g.kind;
+  f.prompt_len = static_cast<int>(g.prompt.size());
+  f.cached_tokens = g.cached;
+  for (auto& c : g.chains) f.chains.push_back({std::move(c.out), c.cum_logprob, c.reason});
+  finished_.push_back(std::move(f));
+  budget_used_ -= g.budget_blocks;
+  running_.erase(std::remove(running_.begin(), running_.end(), gid), running_.end());
+  prefilling_.erase(std::remove(prefilling_.begin(), prefilling_.end(), gid), prefilling_.end());
+  groups_.erase(gid);
+}
+
+void Scheduler::complete_prefill(const StepPlan& plan, const int32_t* first_tokens,
+                                 const float* first_logprobs, int n) {
+  if (plan.kind != StepPlan::Prefill) throw std::logic_error("complete_prefill: not a prefill plan");
+  int cursor = 0;  // into first_tokens, in prefill_sample_layout order
+  std::vector<int> completed;
+  size_t last_j = 0;
+  for (size_t i = 0; i < plan.seq_ids.size(); ++i) {
+    const int gid = plan.request_ids[i];
+    Group& g = groups_.at(gid);
+    const int take = plan.cu_q[i + 1] - plan.cu_q[i];
+    kv_->commit(g.chains[0].seq, g.prompt.data() + g.computed, take);
+    g.computed += take;
+    const bool ends = last_j < plan.last_row_seq.size() && plan.last_row_seq[last_j] == static_cast<int>(i);
+    if (!ends) continue;
+    ++last_j;
+    g.prefilled = true;
+    completed.push_back(gid);
+    if (g.kind != RequestKind::Generate || g.p.max_new_tokens <= 0) {
+      finish_chain(g, g.chains[0], FinishReason::PrefillOnly);
+      continue;
+    }
+    const int seq0 = g.chains[0].seq;
+    g.chains.resize(g.n);
+    for (int k = 1; k < g.n; ++k) g.chains[k].seq = kv_->fork(seq0);
+    for (int k = 0; k < g.n; ++k) {
+      if (cursor >= n) throw std::invalid_argument("complete_prefill: too few sampled tokens");
+      Chain& c = g.chains[k];
+      const int32_t tok = first_tokens[cursor];
+      c.cum_logprob += first_logprobs ? first_logprobs[cursor] : 0.0;
+      ++cursor;
+      c.out.push_back(tok);
+      c.last_token = tok;
+      FinishReason why;
+      if (is_stop(g, tok, &why)) finish_chain(g, c, why);
+      else if (static_cast<int>(c.out.size()) >= g.p.max_new_tokens) finish_chain(g, c, FinishReason::Length);
+    }
+  }
+  for (int gid : completed) {
+    prefilling_.erase(std::remove(prefilling_.begin(), prefilling_.end(), gid), prefilling_.end());
+    running_.push_back(gid);
+    maybe_retire(gid);
+  }
+}
+
+void Scheduler::complete_decode(const StepPlan& plan, const int32_t* tokens, const float* logprobs) {
+  if (plan.kind != StepPlan::Decode) throw std::logic_error("complete_decode: not a decode plan");
+  std::vector<int> touched;
+  size_t row = 0;
+  for (size_t gi = 0; gi < plan.group_first.size(); ++gi) {
+    const int gid = plan.request_ids[plan.group_first[gi]];
+    Group& g = groups_.at(gid);
+    touched.push_back(gid);
+    for (auto& c : g.chains) {
+      if (c.done) continue;
+      if (row >= plan.seq_ids.size() || plan.seq_ids[row] != c.seq)
+        throw std::logic_error("complete_decode: plan does not match scheduler state");
+      kv_->commit(c.seq, &c.last_token, 1);
+      const int32_t tok = tokens[row];
+      c.cum_logprob += logprobs ? logprobs[row] : 0.0;
+      c.out.push_back(tok);
+      c.last_token = tok;
+      FinishReason why;
+      if (is_stop(g, tok, &why)) finish_chain(g, c, why);
+      else if (static_cast<int>(c.out.size()) >= g.p.max_new_tokens) finish_chain(g, c, FinishReason::Length);
+      ++row;
+    }
+  }
+  for (int gid : touched) maybe_retire(gid);
+}
+
+void Scheduler::abort_request(int request_id) {
+  auto it = groups_.find(request_id);
+  if (it == groups_.end()) return;
+  Group& g = it->second;
+  if (!g.admitted) {
+    waiting_.erase(std::remove(waiting_.begin(), waiting_.end(), request_id), waiting_.end());
+    FinishedRequest f;
+    f.request_id = request_id;
+    f.kind = g.kind;
+    f.prompt_len = static_cast<int>(g.prompt.size());
+    f.chains.push_back({{}, 0.0, FinishReason::Aborted});
+    finished_.push_back(std::move(f));
+    groups_.erase(it);
+    return;
+  }
+  for (auto& c : g.chains)
+    if (!c.done) finish_chain(g, c, FinishReason::Aborted);
+  maybe_retire(request_id);
+}
+
+std::vector<FinishedRequest> Scheduler::take_finished() {
+  std::vector<FinishedRequest> out;
+  out.swap(finished_);
+  return out;
+}
+
+}  // namespace lc

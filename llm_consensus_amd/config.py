@@ -1,0 +1,207 @@
+"""Configuration schema.
+
+The reference has no configuration beyond two environment variables
+(``GEMINI_API_KEY``, ``RUST_LOG``; /root/reference/src/main.rs:352-357); personas,
+the round limit (main.rs:300), the poll period and the prompts are literals. Here
+all of that is data. ``ConsensusConfig()`` with no arguments reproduces the
+reference: four personas sharing one model, the unanimity loop, five evaluation
+rounds, a random proposer.
+
+Files may be TOML, JSON or YAML (chosen by extension).
+"""
+from __future__ import annotations
+
+import dataclasses
+import json
+import os
+from dataclasses import dataclass, field
+from pathlib import Path
+from typing import Any, Dict, List, Optional
+
+from ._native import core
+
+STRATEGIES = (
+    "reference_protocol",
+    "majority_vote",
+    "self_consistency",
+    "judge_logprob",
+    "embedding_medoid",
+)
+
+
+@dataclass
+class SamplingConfig:
+    temperature: float = 0.7
+    top_p: float = 0.95
+    top_k: int = 0
+    max_new_tokens: int = 256
+    seed: int = 0
+
+
+@dataclass
+class ModelSpec:
+    """One set of weights. ``path`` is a directory with HF ``config.json`` +
+    ``*.safetensors``; ``preset`` names a built-in architecture for random-init runs."""
+
+    name: str = "default"
+    path: Optional[str] = None
+    preset: Optional[str] = "tiny-llama"
+    dtype: str = "bf16"
+    tp: int = 1
+    ep: int = 1
+    devices: Optional[List[int]] = None
+    kv_block_size: int = 64
+    kv_fraction: float = 0.6          # share of free HBM given to the KV pool
+    max_batch_seqs: int = 256
+    max_prefill_tokens: int = 8192
+    graph_batch_buckets: List[int] = field(default_factory=lambda: [1, 2, 4, 8, 16, 32, 64, 128, 256])
+    tokenizer: Optional[str] = None   # HF tokenizer dir; None => byte-level fallback
+    seed: int = 0                     # random-init seed
+
+
+@dataclass
+class MemberConfig:
+    name: str
+    domain: str = ""
+    tuning: str = ""
+    model: str = "default"            # key into ConsensusConfig.models
+    role: str = "member"              # member | judge | embedder
+    weight: float = 1.0
+
+
+@dataclass
+class ConsensusConfig:
+    strategy: str = "reference_protocol"
+    max_rounds: int = 5
+    proposer_policy: str = "random"   # random | round_robin | fixed | all
+    fixed_proposer: int = 0
+    failure_policy: str = "abstain"   # abstain | needs_refinement
+    parse_mode: str = "strict"        # strict | tolerant
+    decision_mode: str = "text"       # text | logprob (constrained two-way / choice decision on device)
+    forward_reasoning_to_refiner: bool = False
+    k_chains: int = 16
+    choices: str = "ABCD"
+    tie_break: str = "lowest_class"
+    deadline_s: Optional[float] = None
+    seed: int = 0
+    placement: str = "pack"           # pack | spread
+    sampling: SamplingConfig = field(default_factory=SamplingConfig)
+    models: Dict[str, ModelSpec] = field(default_factory=lambda: {"default": ModelSpec()})
+    members: List[MemberConfig] = field(default_factory=list)
+    prompt_propose: Optional[str] = None   # template file paths
+    prompt_evaluate: Optional[str] = None
+    prompt_refine: Optional[str] = None
+    transcript_path: Optional[str] = None  # JSONL dump of rounds/votes/reasoning
+
+    def __post_init__(self) -> None:
+        if not self.members:
+            self.members = [
+                MemberConfig(name=p.name, domain=p.domain, tuning=p.tuning) for p in core.default_personas()
+            ]
+        self.validate()
+
+    # ------------------------------------------------------------------
+    def validate(self) -> None:
+        if self.strategy not in STRATEGIES:
+            raise ValueError(f"unknown strategy {self.strategy!r}; expected one of {STRATEGIES}")
+        if self.max_rounds < 1:
+            raise ValueError("max_rounds must be >= 1")
+        if self.proposer_policy not in ("random", "round_robin", "fixed", "all"):
+            raise ValueError(f"unknown proposer_policy {self.proposer_policy!r}")
+        if self.failure_policy not in ("abstain", "needs_refinement"):
+            raise ValueError(f"unknown failure_policy {self.failure_policy!r}")
+        if self.parse_mode not in ("strict", "tolerant"):
+            raise ValueError(f"unknown parse_mode {self.parse_mode!r}")
+        if self.decision_mode not in ("text", "logprob"):
+            raise ValueError(f"unknown decision_mode {self.decision_mode!r}")
+        names = [m.name for m in self.members]
+        if len(set(names)) != len(names):
+            raise ValueError("member names must be unique (they are registry keys)")
+        for m in self.members:
+            if m.model not in self.models:
+                raise ValueError(f"member {m.name!r} refers to unknown model {m.model!r}")
+
+    def session_config(self) -> "core.SessionConfig":
+        sc = core.SessionConfig()
+        sc.max_rounds = self.max_rounds
+        sc.proposer_policy = {
+            "random": core.ProposerPolicy.Random,
+            "round_robin": core.ProposerPolicy.RoundRobin,
+            "fixed": core.ProposerPolicy.Fixed,
+            "all": core.ProposerPolicy.RoundRobin,
+        }[self.proposer_policy]
+        sc.fixed_proposer = self.fixed_proposer
+        sc.failure_policy = (
+            core.FailurePolicy.Abstain if self.failure_policy == "abstain" else core.FailurePolicy.NeedsRefinement
+        )
+        sc.forward_reasoning_to_refiner = self.forward_reasoning_to_refiner
+        sc.seed = self.seed
+        return sc
+
+    def parse_mode_enum(self) -> "core.ParseMode":
+        return core.ParseMode.Strict if self.parse_mode == "strict" else core.ParseMode.Tolerant
+
+    def tie_break_enum(self) -> "core.TieBreak":
+        return {
+            "lowest_class": core.TieBreak.LowestClass,
+            "first_voter": core.TieBreak.FirstVoter,
+            "highest_weight": core.TieBreak.HighestWeight,
+        }[self.tie_break]
+
+    def templates(self) -> "core.PromptTemplates":
+        t = core.PromptTemplates()
+        for attr, path in (("propose", self.prompt_propose), ("evaluate", self.prompt_evaluate),
+                           ("refine", self.prompt_refine)):
+            if path:
+                setattr(t, attr, Path(path).read_text())
+        return t
+
+    def personas(self) -> List["core.Persona"]:
+        return [core.Persona(m.name, m.domain, m.tuning) for m in self.members]
+
+    def to_dict(self) -> Dict[str, Any]:
+        return dataclasses.asdict(self)
+
+
+def _build(cls, data: Dict[str, Any]):
+    names = {f.name for f in dataclasses.fields(cls)}
+    unknown = set(data) - names
+    if unknown:
+        raise ValueError(f"unknown {cls.__name__} keys: {sorted(unknown)}")
+    return cls(**data)
+
+
+def config_from_dict(d: Dict[str, Any]) -> ConsensusConfig:
+    d = dict(d)
+    if "sampling" in d:
+        d["sampling"] = _build(SamplingConfig, d["sampling"])
+    if "models" in d:
+        models = d["models"]
+        if isinstance(models, list):
+            models = {m["name"]: m for m in models}
+        d["models"] = {k: _build(ModelSpec, {"name": k, **v}) for k, v in models.items()}
+    if "members" in d:
+        d["members"] = [_build(MemberConfig, m) for m in d["members"]]
+    return _build(ConsensusConfig, d)
+
+
+def load_config(path: Optional[str] = None) -> ConsensusConfig:
+    """Loads a config file; ``None`` consults ``$CONSENSUS_CONFIG`` and falls back to
+    the reference-equivalent defaults."""
+    path = path or os.environ.get("CONSENSUS_CONFIG")
+    if not path:
+        return ConsensusConfig()
+    p = Path(path)
+    text = p.read_text()
+    suffix = p.suffix.lower()
+    if suffix == ".toml":
+        import tomli
+
+        data = tomli.loads(text)
+    elif suffix in (".yaml", ".yml"):
+        import yaml
+
+        data = yaml.safe_load(text)
+    else:
+        data = json.loads(text)
+    return config_from_dict(data or {})

@@ -1,0 +1,235 @@
+"""Backend seam: what a member calls to get text, scores or embeddings.
+
+The reference calls a free function ``call_gemini(prompt)`` straight from its actor
+handlers (/root/reference/src/main.rs:82-86, :97, :138, :178): no interface, so no way
+to substitute a fake, and every failure is a panic. ``Backend`` is that missing seam.
+Requests are *submitted* (cheap, returns a handle) and completed by ``run()``, so a
+driver can queue work from many sessions and members before the engine batches it.
+
+Implementations: ``EngineBackend`` (llm_consensus_amd/engine/backend.py, the in-process
+MI355X engine), ``ScriptedBackend`` (canned replies + fault injection for protocol
+tests) and ``CallableBackend`` (wraps any ``str -> str`` function).
+"""
+from __future__ import annotations
+
+import time
+from dataclasses import dataclass, field
+from typing import Any, Callable, Dict, List, Optional, Sequence
+
+
+class BackendError(RuntimeError):
+    """A request failed (timeout, engine fault, injected failure)."""
+
+
+@dataclass
+class GenParams:
+    temperature: float = 0.7
+    top_p: float = 0.95
+    top_k: int = 0
+    max_new_tokens: int = 256
+    seed: int = 0
+    n: int = 1                                  # chains forked from the prompt
+    decision_targets: Optional[List[str]] = None  # if set, also return log-probs of these continuations
+    #                                               at the position after the generated text
+
+
+@dataclass
+class GenResult:
+    texts: List[str]                            # one per chain
+    token_ids: List[List[int]] = field(default_factory=list)
+    cum_logprobs: List[float] = field(default_factory=list)
+    decision_logprobs: Optional[List[List[float]]] = None  # [chain][target]
+    prompt_tokens: int = 0
+    cached_tokens: int = 0
+
+
+class Handle:
+    """Result slot for one submitted request."""
+
+    __slots__ = ("_value", "_error", "_done", "submitted_at", "finished_at", "tag")
+
+    def __init__(self, tag: Any = None) -> None:
+        self._value = None
+        self._error: Optional[BaseException] = None
+        self._done = False
+        self.submitted_at = time.perf_counter()
+        self.finished_at: Optional[float] = None
+        self.tag = tag
+
+    def set_result(self, value: Any) -> None:
+        self._value, self._done, self.finished_at = value, True, time.perf_counter()
+
+    def set_error(self, err: BaseException) -> None:
+        self._error, self._done, self.finished_at = err, True, time.perf_counter()
+
+    @property
+    def done(self) -> bool:
+        return self._done
+
+    @property
+    def failed(self) -> bool:
+        return self._done and self._error is not None
+
+    def result(self) -> Any:
+        if not self._done:
+            raise BackendError("result() called before the backend ran this request")
+        if self._error is not None:
+            raise BackendError(str(self._error)) from self._error
+        return self._value
+
+
+class Backend:
+    """Text-level LLM service. All submit_* are non-blocking; run() completes them."""
+
+    name = "backend"
+
+    def submit_generate(self, prompt: str, params: GenParams) -> Handle:
+        raise NotImplementedError
+
+    def submit_score(self, prompt: str, targets: Sequence[str]) -> Handle:
+        """Log-probability of each target continuation (its first token) after ``prompt``.
+        Result: ``List[float]`` aligned with ``targets``."""
+        raise NotImplementedError
+
+    def submit_embed(self, text: str) -> Handle:
+        """Pooled, L2-normalised embedding of ``text``. Result: ``List[float]`` / ndarray."""
+        raise NotImplementedError
+
+    def run(self) -> None:
+        """Drive the backend until every submitted handle is done."""
+        raise NotImplementedError
+
+    def stats(self) -> Dict[str, float]:
+        return {}
+
+
+class CallableBackend(Backend):
+    """Wraps ``fn(prompt) -> str``; generation only."""
+
+    def __init__(self, fn: Callable[[str], str], name: str = "callable") -> None:
+        self.fn = fn
+        self.name = name
+        self._queue: List[tuple] = []
+
+    def submit_generate(self, prompt: str, params: GenParams) -> Handle:
+        h = Handle()
+        self._queue.append((h, prompt, params))
+        return h
+
+    def run(self) -> None:
+        q, self._queue = self._queue, []
+        for h, prompt, params in q:
+            try:
+                h.set_result(GenResult(texts=[self.fn(prompt) for _ in range(max(1, params.n))]))
+            except Exception as e:  # surfaced as a member failure, never a crash
+                h.set_error(e)
+
+
+class ScriptedBackend(Backend):
+    """Fake backend for protocol tests.
+
+    ``script`` maps a role to a list of replies consumed in order, or to a callable
+    ``(prompt) -> reply``. Roles are detected from the rendered prompt: the evaluate
+    template contains "Good or NeedsRefinement" style instructions, the refine template
+    mentions refinement, everything else is a proposal. Fault injection:
+
+    * ``fail_every``   -- every n-th request raises (a dropped reply);
+    * ``garbage_every``-- every n-th evaluate reply is replaced by unparseable text;
+    * ``delay_s``      -- sleep per request (a slow member).
+    """
+
+    def __init__(
+        self,
+        script: Optional[Dict[str, Any]] = None,
+        default_verdict: str = "Good",
+        fail_every: int = 0,
+        garbage_every: int = 0,
+        delay_s: float = 0.0,
+        scores: Optional[Callable[[str, Sequence[str]], List[float]]] = None,
+        embed: Optional[Callable[[str], List[float]]] = None,
+        name: str = "scripted",
+    ) -> None:
+        self.script = {k: (list(v) if isinstance(v, (list, tuple)) else v) for k, v in (script or {}).items()}
+        self.default_verdict = default_verdict
+        self.fail_every = fail_every
+        self.garbage_every = garbage_every
+        self.delay_s = delay_s
+        self.scores = scores
+        self.embed = embed
+        self.name = name
+        self.calls: List[tuple] = []      # (role, prompt) log for assertions
+        self._queue: List[tuple] = []
+        self._count = 0
+        self._eval_count = 0
+
+    @staticmethod
+    def role_of(prompt: str) -> str:
+        if "Your Instructions:" in prompt:
+            head = prompt.split("Your Instructions:", 1)[1]
+            return "refine" if "Examples:" not in head else "evaluate"
+        return "propose"
+
+    def _next(self, role: str, prompt: str) -> str:
+        src = self.script.get(role)
+        if callable(src):
+            return src(prompt)
+        if src:
+            return src.pop(0) if len(src) > 1 else src[0]
+        if role == "evaluate":
+            return f"{self.default_verdict}\nscripted reasoning"
+        if role == "refine":
+            return "refined answer"
+        return "proposed answer"
+
+    def submit_generate(self, prompt: str, params: GenParams) -> Handle:
+        h = Handle()
+        self._queue.append(("gen", h, prompt, params))
+        return h
+
+    def submit_score(self, prompt: str, targets: Sequence[str]) -> Handle:
+        h = Handle()
+        self._queue.append(("score", h, prompt, list(targets)))
+        return h
+
+    def submit_embed(self, text: str) -> Handle:
+        h = Handle()
+        self._queue.append(("embed", h, text, None))
+        return h
+
+    def run(self) -> None:
+        q, self._queue = self._queue, []
+        for kind, h, prompt, extra in q:
+            self._count += 1
+            if self.delay_s:
+                time.sleep(self.delay_s)
+            if self.fail_every and self._count % self.fail_every == 0:
+                h.set_error(BackendError("injected failure"))
+                continue
+            try:
+                if kind == "gen":
+                    role = self.role_of(prompt)
+                    self.calls.append((role, prompt))
+                    n = max(1, extra.n)
+                    texts = []
+                    for _ in range(n):
+                        reply = self._next(role, prompt)
+                        if role == "evaluate":
+                            self._eval_count += 1
+                            if self.garbage_every and self._eval_count % self.garbage_every == 0:
+                                reply = "I would rather not say."
+                        texts.append(reply)
+                    dec = None
+                    if extra.decision_targets:
+                        fn = self.scores or (lambda p, t: [0.0] + [-1.0] * (len(t) - 1))
+                        dec = [list(fn(prompt + x, extra.decision_targets)) for x in texts]
+                    h.set_result(GenResult(texts=texts, decision_logprobs=dec))
+                elif kind == "score":
+                    self.calls.append(("score", prompt))
+                    fn = self.scores or (lambda p, t: [0.0] + [-1.0] * (len(t) - 1))
+                    h.set_result(list(fn(prompt, extra)))
+                else:
+                    self.calls.append(("embed", prompt))
+                    fn = self.embed or (lambda t: [float(len(t) % 7), 1.0, float(t.count("a"))])
+                    h.set_result(list(fn(prompt)))
+            except Exception as e:
+                h.set_error(e)

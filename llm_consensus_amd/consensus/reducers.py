@@ -1,0 +1,86 @@
+"""Batched consensus reducers with host and device execution.
+
+``device=None`` runs the native host implementations (csrc/core/reducers.cpp), which
+define the semantics. With a ``torch.device('cuda')`` the gfx950 kernels in
+csrc/kernels/consensus.hip run instead: one wave per request for the vote histogram,
+one MFMA tile per request for the cosine medoid. The reference's only reducer is
+"all votes are Good" (/root/reference/src/main.rs:266, :323); it is available here as
+``unanimity`` over two-way verdict log-probs.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Optional
+
+import numpy as np
+
+from .._native import core
+
+
+@dataclass
+class VoteBatch:
+    winner: np.ndarray      # [R] int32, -1 when a row has no valid vote
+    count: np.ndarray       # [R] int32
+    valid: np.ndarray       # [R] int32
+    agreement: np.ndarray   # [R] float32
+    unanimous: np.ndarray   # [R] bool
+
+
+@dataclass
+class JudgeBatch:
+    winner: np.ndarray      # [R] int32
+    score: np.ndarray       # [R] float32
+    unanimous: np.ndarray   # [R] bool
+
+
+def _is_gpu(device) -> bool:
+    return device is not None and str(device).startswith("cuda")
+
+
+def majority_vote_batch(votes: np.ndarray, num_classes: int,
+                        tie: "core.TieBreak" = core.TieBreak.LowestClass, device=None) -> VoteBatch:
+    votes = np.ascontiguousarray(votes, dtype=np.int32)
+    if votes.ndim != 2:
+        raise ValueError("votes must be [R, N]")
+    if _is_gpu(device):
+        from ..ops import consensus_ops
+
+        return consensus_ops.majority_vote_device(votes, num_classes, tie, device)
+    res = core.majority_vote_batch(votes, num_classes, tie)
+    return VoteBatch(
+        winner=np.array([r.winner for r in res], dtype=np.int32),
+        count=np.array([r.count for r in res], dtype=np.int32),
+        valid=np.array([r.valid for r in res], dtype=np.int32),
+        agreement=np.array([r.agreement for r in res], dtype=np.float32),
+        unanimous=np.array([r.unanimous for r in res], dtype=bool),
+    )
+
+
+def cosine_medoid(E: np.ndarray, device=None) -> "core.MedoidResult":
+    E = np.ascontiguousarray(E, dtype=np.float32)
+    if _is_gpu(device):
+        from ..ops import consensus_ops
+
+        return consensus_ops.cosine_medoid_device(E, device)
+    return core.cosine_medoid(E)
+
+
+def judge_reduce_batch(scores: np.ndarray, device=None) -> JudgeBatch:
+    scores = np.ascontiguousarray(scores, dtype=np.float32)
+    if scores.ndim != 3:
+        raise ValueError("scores must be [R, C, J]")
+    if _is_gpu(device):
+        from ..ops import consensus_ops
+
+        return consensus_ops.judge_reduce_device(scores, device)
+    res = [core.judge_reduce(s) for s in scores]
+    return JudgeBatch(
+        winner=np.array([r.winner for r in res], dtype=np.int32),
+        score=np.array([r.score for r in res], dtype=np.float32),
+        unanimous=np.array([r.unanimous for r in res], dtype=bool),
+    )
+
+
+def unanimity(verdict_logprobs: np.ndarray) -> "core.UnanimityResult":
+    """[N, 2] (log P Good, log P NeedsRefinement) -> all_good flag + dissenters."""
+    return core.unanimity_from_logprobs(np.ascontiguousarray(verdict_logprobs, dtype=np.float32))

@@ -1,0 +1,315 @@
+"""Consensus strategies beyond the reference's unanimity loop.
+
+The reference implements exactly one reducer: every member voted Good
+(/root/reference/src/main.rs:266, :323). The strategies here cover the other ways an
+ensemble can agree:
+
+* ``MajorityVote``      -- every member answers; answers are mapped to class ids
+                           (parsed text or an on-device choice-logprob decision) and
+                           the plurality class wins.
+* ``SelfConsistency``   -- one member samples K chains from one prompt (shared-prefix
+                           KV); the plurality answer over chains wins.
+* ``JudgeLogprob``      -- proposers answer, judge members score every candidate by
+                           log P(accept) - log P(reject); best mean score wins.
+* ``EmbeddingMedoid``   -- proposers answer, an embedding member embeds the
+                           candidates; the candidate most similar to the rest wins.
+
+All of them process a *batch* of questions: requests of every question and member are
+queued first and each backend runs once per phase, so the engines see large batches.
+Reducers run on device when a ``device`` is given (HIP kernels in
+csrc/kernels/consensus.hip) and in the native host core otherwise.
+"""
+from __future__ import annotations
+
+import time
+from typing import Callable, List, Optional, Sequence
+
+import numpy as np
+
+from .._native import core
+from ..utils.log import get_logger
+from . import reducers
+from .backend import BackendError, GenParams
+from .members import Member, distinct_backends
+from .protocol import ConsensusResult
+
+log = get_logger("consensus.strategy")
+
+
+def _run_all(members: Sequence[Member]) -> None:
+    for b in distinct_backends(list(members)):
+        b.run()
+
+
+def _classify(text: str, decision_lp: Optional[List[float]], choices: str) -> int:
+    if decision_lp is not None:
+        return int(np.argmax(np.asarray(decision_lp, dtype=np.float32)))
+    return core.extract_choice(text, choices)
+
+
+class MajorityVote:
+    name = "majority_vote"
+
+    def __init__(self, members: Sequence[Member], choices: str = "ABCD",
+                 tie_break: "core.TieBreak" = core.TieBreak.LowestClass,
+                 decision_mode: str = "text", params: Optional[GenParams] = None,
+                 prompt_fn: Optional[Callable[[str], str]] = None, device=None) -> None:
+        if not members:
+            raise ValueError("MajorityVote needs at least one member")
+        self.members = list(members)
+        self.choices = choices
+        self.tie_break = tie_break
+        self.decision_mode = decision_mode
+        self.params = params
+        self.prompt_fn = prompt_fn or (lambda q: q)
+        self.device = device
+
+    def _member_params(self, m: Member) -> GenParams:
+        p = self.params or m.params
+        if self.decision_mode == "logprob":
+            p = GenParams(**{**p.__dict__, "decision_targets": [" " + c for c in self.choices]})
+        return p
+
+    def ask_many(self, questions: Sequence[str]) -> List[ConsensusResult]:
+        t0 = time.perf_counter()
+        handles = [[m.submit_prompt(self.prompt_fn(q), self._member_params(m)) for m in self.members]
+                   for q in questions]
+        _run_all(self.members)
+        R, N = len(questions), len(self.members)
+        votes = np.full((R, N), -1, dtype=np.int32)
+        texts = [[""] * N for _ in range(R)]
+        for r in range(R):
+            for i in range(N):
+                try:
+                    res = handles[r][i].result()
+                except BackendError as e:
+                    log.error("%s failed: %s", self.members[i].name, e)
+                    continue
+                texts[r][i] = res.texts[0]
+                dec = res.decision_logprobs[0] if res.decision_logprobs else None
+                votes[r, i] = _classify(res.texts[0], dec, self.choices)
+        red = reducers.majority_vote_batch(votes, len(self.choices), self.tie_break, device=self.device)
+        dt = time.perf_counter() - t0
+        out = []
+        for r, q in enumerate(questions):
+            w = int(red.winner[r])
+            out.append(ConsensusResult(
+                question=q,
+                answer=self.choices[w] if w >= 0 else "",
+                strategy=self.name,
+                rounds=1,
+                member_calls=N,
+                unanimous=bool(red.unanimous[r]),
+                latency_s=max((h.finished_at or t0) for h in handles[r]) - t0 if handles[r] else dt,
+                agreement=float(red.agreement[r]),
+                votes=[{"member": m.name, "class": int(votes[r, i]), "text": texts[r][i]}
+                       for i, m in enumerate(self.members)],
+            ))
+        return out
+
+    def ask(self, question: str) -> ConsensusResult:
+        return self.ask_many([question])[0]
+
+
+class SelfConsistency:
+    name = "self_consistency"
+
+    def __init__(self, member: Member, k_chains: int = 16, choices: str = "ABCD",
+                 tie_break: "core.TieBreak" = core.TieBreak.LowestClass,
+                 decision_mode: str = "text", params: Optional[GenParams] = None,
+                 prompt_fn: Optional[Callable[[str], str]] = None, numeric: bool = False,
+                 device=None) -> None:
+        self.member = member
+        self.k = k_chains
+        self.choices = choices
+        self.tie_break = tie_break
+        self.decision_mode = decision_mode
+        self.params = params
+        self.prompt_fn = prompt_fn or (lambda q: q)
+        self.numeric = numeric
+        self.device = device
+
+    def ask_many(self, questions: Sequence[str]) -> List[ConsensusResult]:
+        t0 = time.perf_counter()
+        base = self.params or self.member.params
+        handles = []
+        for qi, q in enumerate(questions):
+            p = GenParams(**{**base.__dict__, "n": self.k, "seed": base.seed + 1000003 * qi})
+            if self.decision_mode == "logprob" and not self.numeric:
+                p.decision_targets = [" " + c for c in self.choices]
+            handles.append(self.member.submit_prompt(self.prompt_fn(q), p))
+        _run_all([self.member])
+        R = len(questions)
+        votes = np.full((R, self.k), -1, dtype=np.int32)
+        labels: List[List[str]] = [[] for _ in range(R)]  # class id -> answer string (free-form mode)
+        chains_text: List[List[str]] = [[] for _ in range(R)]
+        cached = [0] * R
+        for r in range(R):
+            try:
+                res = handles[r].result()
+            except BackendError as e:
+                log.error("%s failed: %s", self.member.name, e)
+                continue
+            cached[r] = res.cached_tokens
+            chains_text[r] = list(res.texts)
+            for c, text in enumerate(res.texts[: self.k]):
+                if self.numeric:
+                    v = core.extract_number(text)
+                    if v is None:
+                        continue
+                    key = repr(float(v))
+                    if key not in labels[r]:
+                        labels[r].append(key)
+                    votes[r, c] = labels[r].index(key)
+                else:
+                    dec = res.decision_logprobs[c] if res.decision_logprobs else None
+                    votes[r, c] = _classify(text, dec, self.choices)
+        ncls = max(len(self.choices), max((len(l) for l in labels), default=0), 1)
+        red = reducers.majority_vote_batch(votes, ncls, self.tie_break, device=self.device)
+        out = []
+        for r, q in enumerate(questions):
+            w = int(red.winner[r])
+            if w < 0:
+                ans = ""
+            elif self.numeric:
+                ans = labels[r][w]
+            else:
+                ans = self.choices[w]
+            out.append(ConsensusResult(
+                question=q, answer=ans, strategy=self.name, rounds=1, member_calls=self.k,
+                unanimous=bool(red.unanimous[r]),
+                latency_s=(handles[r].finished_at or time.perf_counter()) - t0,
+                agreement=float(red.agreement[r]),
+                votes=[{"chain": c, "class": int(votes[r, c])} for c in range(self.k)],
+                extra={"cached_prompt_tokens": cached[r], "chains": chains_text[r]},
+            ))
+        return out
+
+    def ask(self, question: str) -> ConsensusResult:
+        return self.ask_many([question])[0]
+
+
+class JudgeLogprob:
+    name = "judge_logprob"
+    JUDGE_TARGETS = [" Yes", " No"]
+
+    def __init__(self, proposers: Sequence[Member], judges: Sequence[Member],
+                 params: Optional[GenParams] = None, device=None) -> None:
+        if not proposers or not judges:
+            raise ValueError("JudgeLogprob needs proposers and at least one judge")
+        self.proposers = list(proposers)
+        self.judges = list(judges)
+        self.params = params
+        self.device = device
+
+    @staticmethod
+    def judge_prompt(question: str, candidate: str) -> str:
+        return (f"Question: {question}\nProposed answer: {candidate}\n"
+                "Is the proposed answer correct and complete? Reply Yes or No.\nVerdict:")
+
+    def ask_many(self, questions: Sequence[str]) -> List[ConsensusResult]:
+        t0 = time.perf_counter()
+        prop = [[m.submit_propose(q, self.params) for m in self.proposers] for q in questions]
+        _run_all(self.proposers)
+        cands: List[List[str]] = []
+        for r in range(len(questions)):
+            row = []
+            for i, h in enumerate(prop[r]):
+                try:
+                    row.append(Member.finish_text(h))
+                except BackendError as e:
+                    log.error("%s failed: %s", self.proposers[i].name, e)
+                    row.append("")
+            cands.append(row)
+        score_h = [[[j.backend.submit_score(self.judge_prompt(q, c), self.JUDGE_TARGETS) for j in self.judges]
+                    for c in cands[r]] for r, q in enumerate(questions)]
+        _run_all(self.judges)
+        C, J = len(self.proposers), len(self.judges)
+        scores = np.full((len(questions), C, J), -1e30, dtype=np.float32)
+        for r in range(len(questions)):
+            for c in range(C):
+                if not cands[r][c]:
+                    continue
+                for j in range(J):
+                    try:
+                        lp = score_h[r][c][j].result()
+                        scores[r, c, j] = float(lp[0]) - float(lp[1])
+                    except BackendError as e:
+                        log.error("%s failed to score: %s", self.judges[j].name, e)
+                        scores[r, c, j] = 0.0
+        red = reducers.judge_reduce_batch(scores, device=self.device)
+        out = []
+        for r, q in enumerate(questions):
+            w = int(red.winner[r])
+            out.append(ConsensusResult(
+                question=q, answer=cands[r][w] if w >= 0 else "", strategy=self.name, rounds=1,
+                member_calls=C + C * J, unanimous=bool(red.unanimous[r]),
+                proposer=self.proposers[w].name if w >= 0 else None,
+                latency_s=time.perf_counter() - t0,
+                votes=[{"candidate": self.proposers[c].name, "scores": scores[r, c].tolist()} for c in range(C)],
+                extra={"winner_score": float(red.score[r])},
+            ))
+        return out
+
+    def ask(self, question: str) -> ConsensusResult:
+        return self.ask_many([question])[0]
+
+
+class EmbeddingMedoid:
+    name = "embedding_medoid"
+
+    def __init__(self, proposers: Sequence[Member], embedder: Member,
+                 params: Optional[GenParams] = None, samples_per_member: int = 1, device=None) -> None:
+        if not proposers:
+            raise ValueError("EmbeddingMedoid needs proposers")
+        self.proposers = list(proposers)
+        self.embedder = embedder
+        self.params = params
+        self.samples = samples_per_member
+        self.device = device
+
+    def ask_many(self, questions: Sequence[str]) -> List[ConsensusResult]:
+        t0 = time.perf_counter()
+        prop = []
+        for q in questions:
+            row = []
+            for m in self.proposers:
+                p = self.params or m.params
+                if self.samples > 1:
+                    p = GenParams(**{**p.__dict__, "n": self.samples})
+                row.append(m.submit_propose(q, p))
+            prop.append(row)
+        _run_all(self.proposers)
+        cands: List[List[str]] = []
+        owners: List[List[str]] = []
+        for r in range(len(questions)):
+            row, own = [], []
+            for i, h in enumerate(prop[r]):
+                try:
+                    for t in h.result().texts:
+                        row.append(t)
+                        own.append(self.proposers[i].name)
+                except BackendError as e:
+                    log.error("%s failed: %s", self.proposers[i].name, e)
+            cands.append(row)
+            owners.append(own)
+        emb_h = [[self.embedder.backend.submit_embed(c) for c in cands[r]] for r in range(len(questions))]
+        _run_all([self.embedder])
+        out = []
+        for r, q in enumerate(questions):
+            if not cands[r]:
+                out.append(ConsensusResult(question=q, answer="", strategy=self.name, extra={"error": "no candidates"}))
+                continue
+            E = np.stack([np.asarray(h.result(), dtype=np.float32) for h in emb_h[r]])
+            red = reducers.cosine_medoid(E, device=self.device)
+            out.append(ConsensusResult(
+                question=q, answer=cands[r][red.index], strategy=self.name, rounds=1,
+                member_calls=len(self.proposers) + len(cands[r]), proposer=owners[r][red.index],
+                latency_s=time.perf_counter() - t0, agreement=float(red.mean_pairwise),
+                votes=[{"candidate": owners[r][i], "text": c} for i, c in enumerate(cands[r])],
+                extra={"medoid_score": float(red.score)},
+            ))
+        return out
+
+    def ask(self, question: str) -> ConsensusResult:
+        return self.ask_many([question])[0]

@@ -1,0 +1,190 @@
+"""Paged-KV bookkeeping and the continuous-batching scheduler (CPU only)."""
+import numpy as np
+import pytest
+from hypothesis import given, settings, strategies as st
+
+from llm_consensus_amd._native import core
+
+
+def toks(n, start=0):
+    return np.arange(start, start + n, dtype=np.int32)
+
+
+def test_alloc_fork_cow_and_free():
+    kv = core.KVManager(16, 4, False)
+    s, cached = kv.create_sequence(toks(6))
+    assert cached == 0 and len(kv.block_table(s)) == 2
+    kv.commit(s, toks(6))
+    f = kv.fork(s)
+    assert kv.block_table(f) == kv.block_table(s) and kv.shared_prefix_blocks(s) == 2
+    # both chains append into the shared partial tail block -> first writer copies
+    assert kv.reserve(s, 1)
+    copies = kv.take_pending_copies()
+    assert len(copies) == 1 and copies[0][0] == kv.block_table(f)[1] and copies[0][1] == kv.block_table(s)[1]
+    assert kv.block_table(s)[0] == kv.block_table(f)[0]          # full block stays shared
+    assert kv.reserve(f, 1) and kv.take_pending_copies() == []    # last owner writes in place
+    st0 = kv.stats()
+    assert st0.cow_copies == 1
+    kv.free_sequence(s); kv.free_sequence(f)
+    assert kv.stats().blocks_free == 16
+
+
+def test_prefix_cache_hits_full_blocks_only_and_keeps_one_token():
+    kv = core.KVManager(32, 4, True)
+    a, c = kv.create_sequence(toks(10))
+    assert c == 0
+    kv.commit(a, toks(10))
+    b, c = kv.create_sequence(np.concatenate([toks(8), toks(5, 100)]))
+    assert c == 8 and kv.block_table(b)[:2] == kv.block_table(a)[:2]
+    # identical prompt of exactly 2 blocks: last block is recomputed so a logit exists
+    d, c = kv.create_sequence(toks(8))
+    assert c == 4
+    st = kv.stats()
+    assert st.prefix_hit_tokens == 12 and st.prompt_tokens == 10 + 13 + 8
+    kv.free_sequence(a)
+    # cached blocks survive their owner and are evictable
+    e, c = kv.create_sequence(toks(9))
+    assert c == 8
+
+
+def test_eviction_under_pressure_and_exhaustion():
+    kv = core.KVManager(4, 4, True)
+    a, _ = kv.create_sequence(toks(8)); kv.commit(a, toks(8)); kv.free_sequence(a)
+    assert kv.stats().blocks_free == 2 and kv.available_blocks() == 4
+    b, c = kv.create_sequence(toks(16, 500))     # needs all 4 blocks -> evicts the cache
+    assert b >= 0 and c == 0 and kv.stats().evictions == 2
+    x, _ = kv.create_sequence(toks(4, 900))
+    assert x == -1                               # nothing leaked on failure
+    kv.free_sequence(b)
+    assert kv.available_blocks() == 4
+
+
+@settings(max_examples=50, deadline=None)
+@given(st.lists(st.tuples(st.integers(0, 3), st.integers(1, 20)), min_size=1, max_size=60))
+def test_refcounts_never_leak(ops):
+    kv = core.KVManager(64, 4, True)
+    live = []
+    for op, n in ops:
+        if op == 0 or not live:
+            s, c = kv.create_sequence(toks(n, n * 3))
+            if s >= 0:
+                kv.commit(s, toks(n, n * 3)[c:])
+                live.append(s)
+        elif op == 1:
+            live.append(kv.fork(live[n % len(live)]))
+        elif op == 2:
+            s = live[n % len(live)]
+            if kv.reserve(s, 1):
+                kv.commit(s, toks(1, 7))
+        else:
+            kv.free_sequence(live.pop(n % len(live)))
+        kv.take_pending_copies()
+    for s in live:
+        kv.free_sequence(s)
+    assert kv.available_blocks() == 64
+
+
+# ---------------------------------------------------------------- scheduler
+
+def run_to_completion(sched, vocab=50, max_steps=10_000):
+    """Drives the scheduler with a fake model: next token = (last + 1) % vocab."""
+    finished = []
+    steps = {"prefill": 0, "decode": 0, "max_batch": 0, "max_prefill_tokens": 0, "shared": 0}
+    for _ in range(max_steps):
+        plan = sched.schedule()
+        if plan.kind == core.StepPlan.Kind.Idle:
+            break
+        if plan.kind == core.StepPlan.Kind.Prefill:
+            steps["prefill"] += 1
+            steps["max_prefill_tokens"] = max(steps["max_prefill_tokens"], len(plan.token_ids))
+            assert plan.cu_q[-1] == len(plan.token_ids) == len(plan.positions) == len(plan.slot_mapping)
+            slots = sched.prefill_sample_layout(plan)
+            first = [(int(plan.token_ids[plan.last_rows[s.last_row_index]]) + 1 + s.chain) % vocab for s in slots]
+            sched.complete_prefill(plan, np.array(first, dtype=np.int32), np.zeros(len(first), dtype=np.float32))
+        else:
+            steps["decode"] += 1
+            B = len(plan.seq_ids)
+            steps["max_batch"] = max(steps["max_batch"], B)
+            steps["shared"] += int(sum(plan.group_shared_blocks))
+            assert plan.block_tables.shape == (B, plan.max_blocks)
+            assert (plan.context_lens == plan.positions + 1).all()
+            assert sum(plan.group_count) == B
+            nxt = (plan.token_ids + 1) % vocab
+            sched.complete_decode(plan, nxt.astype(np.int32), np.full(B, -0.5, dtype=np.float32))
+        finished += sched.take_finished()
+    assert not sched.has_work()
+    return finished, steps
+
+
+def make_sched(blocks=256, bs=4, max_batch=8, max_prefill=16, cache=True):
+    kv = core.KVManager(blocks, bs, cache)
+    cfg = core.SchedulerConfig()
+    cfg.max_batch_seqs, cfg.max_prefill_tokens = max_batch, max_prefill
+    return core.Scheduler(kv, cfg), kv
+
+
+def test_generate_lengths_chunked_prefill_and_batch_cap():
+    sched, kv = make_sched()
+    p = core.SamplingParams(); p.max_new_tokens = 5
+    ids = [sched.add_request(core.RequestKind.Generate, toks(10 + i, 3 * i), 1, p) for i in range(12)]
+    fin, steps = run_to_completion(sched)
+    assert sorted(f.request_id for f in fin) == ids
+    for f in fin:
+        assert len(f.chains) == 1 and len(f.chains[0].tokens) == 5
+        assert f.chains[0].reason == core.FinishReason.Length
+        t = f.chains[0].tokens
+        assert all((t[i + 1] - t[i]) % 50 == 1 for i in range(4))
+        assert abs(f.chains[0].cum_logprob - (-0.5 * 4)) < 1e-6
+    assert steps["max_batch"] <= 8 and steps["max_prefill_tokens"] <= 16 and steps["prefill"] > 1
+    assert kv.available_blocks() == 256
+
+
+def test_forked_chains_share_prefix_blocks_and_eos_stops():
+    sched, kv = make_sched(max_batch=16, max_prefill=64)
+    p = core.SamplingParams(); p.max_new_tokens = 6; p.eos_id = 13
+    rid = sched.add_request(core.RequestKind.Generate, toks(10), 4, p)   # last prompt token 9 -> chains start 10..13
+    fin, steps = run_to_completion(sched)
+    assert len(fin) == 1 and fin[0].request_id == rid and len(fin[0].chains) == 4
+    firsts = [c.tokens[0] for c in fin[0].chains]
+    assert firsts == [10, 11, 12, 13]
+    assert fin[0].chains[3].reason == core.FinishReason.Eos and len(fin[0].chains[3].tokens) == 1
+    assert fin[0].chains[0].reason == core.FinishReason.Eos and fin[0].chains[0].tokens[-1] == 13
+    assert steps["shared"] > 0                  # 2 full prompt blocks are shared by the group
+    assert kv.stats().cow_copies >= 2 and kv.available_blocks() == 256
+
+
+def test_score_and_embed_requests_finish_after_prefill():
+    sched, kv = make_sched()
+    a = sched.add_request(core.RequestKind.Score, toks(7))
+    b = sched.add_request(core.RequestKind.Embed, toks(9))
+    fin, steps = run_to_completion(sched)
+    assert {f.request_id for f in fin} == {a, b} and steps["decode"] == 0
+    assert all(f.chains[0].reason == core.FinishReason.PrefillOnly for f in fin)
+
+
+def test_admission_respects_kv_budget_and_abort():
+    sched, kv = make_sched(blocks=8, bs=4, max_batch=8, max_prefill=64)
+    p = core.SamplingParams(); p.max_new_tokens = 8
+    ids = [sched.add_request(core.RequestKind.Generate, toks(8, 10 * i), 1, p) for i in range(4)]
+    plan = sched.schedule()
+    assert len(plan.seq_ids) == 2 and sched.num_waiting == 2     # each needs 4 blocks of the 8
+    sched.abort_request(ids[3])
+    with pytest.raises(ValueError):
+        sched.add_request(core.RequestKind.Generate, toks(64), 1, p)
+    slots = sched.prefill_sample_layout(plan)
+    sched.complete_prefill(plan, np.zeros(len(slots), np.int32), np.zeros(len(slots), np.float32))
+    fin, _ = run_to_completion(sched)
+    done = {f.request_id for f in fin} | {f.request_id for f in sched.take_finished()}
+    assert set(ids[:3]) <= done
+
+
+def test_prefix_cache_across_requests():
+    sched, kv = make_sched(max_prefill=64)
+    p = core.SamplingParams(); p.max_new_tokens = 2
+    shared = toks(16)
+    sched.add_request(core.RequestKind.Generate, np.concatenate([shared, toks(3, 100)]), 1, p)
+    run_to_completion(sched)
+    sched.add_request(core.RequestKind.Generate, np.concatenate([shared, toks(5, 200)]), 1, p)
+    fin, _ = run_to_completion(sched)
+    assert fin[0].cached_tokens == 16
+    assert kv.stats().prefix_hit_tokens == 16

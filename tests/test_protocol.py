@@ -1,0 +1,195 @@
+"""Protocol parity with the reference Coordinator (/root/reference/src/main.rs:187-345)."""
+import pytest
+from hypothesis import given, settings, strategies as st
+
+from llm_consensus_amd._native import core
+from llm_consensus_amd.consensus.backend import ScriptedBackend
+from llm_consensus_amd.consensus.members import Member
+from llm_consensus_amd.consensus.protocol import Coordinator
+
+K = core.Action.Kind
+V = core.Verdict
+NAMES = ["a", "b", "c", "d"]
+
+
+def drive(session, verdict_fn, max_steps=1000):
+    """Runs a session with scripted votes; returns (#propose, #evaluate, #refine)."""
+    a = session.ask("q")
+    n_prop = n_eval = n_ref = 0
+    steps = 0
+    while a.kind != K.Done:
+        steps += 1
+        assert steps < max_steps, "protocol did not terminate"
+        if a.kind == K.Propose:
+            assert 0 <= a.member < session.num_members
+            n_prop += 1
+            a = session.on_proposal("answer0")
+        elif a.kind == K.Evaluate:
+            rnd = session.evaluation_count
+            for i in range(session.num_members):
+                n_eval += 1
+                a = session.on_evaluation(i, verdict_fn(rnd, i), "why")
+                if i < session.num_members - 1:
+                    assert a.kind == K.None_
+        elif a.kind == K.Refine:
+            votes = {v.member: v.verdict for v in session.transcript[-1].votes}
+            assert votes[a.member] == V.NeedsRefinement          # refiner is a dissenter (main.rs:268-272)
+            n_ref += 1
+            a = session.on_refinement(f"answer{n_ref}")
+        else:
+            raise AssertionError(a.kind)
+    return n_prop, n_eval, n_ref
+
+
+def test_happy_path_is_one_plus_n_calls():
+    s = core.ConsensusSession(NAMES)
+    assert drive(s, lambda r, i: V.Good) == (1, 4, 0)
+    assert s.ready() and s.answer() == "answer0" and s.evaluation_count == 1 and s.member_calls == 5
+    assert not s.forced
+
+
+def test_worst_case_round_accounting():
+    # 5 evaluation rounds, the 5th refinement is accepted unevaluated (main.rs:300-311)
+    s = core.ConsensusSession(NAMES)
+    assert drive(s, lambda r, i: V.NeedsRefinement) == (1, 20, 5)
+    assert s.evaluation_count == 5 and s.member_calls == 26
+    assert s.forced and s.ready() and s.answer() == "answer5"
+
+
+def test_readiness_predicate_and_not_ready_literal():
+    s = core.ConsensusSession(NAMES)
+    assert not s.ready()
+    assert s.answer() == "System error: Requested answer when answer was not ready."   # main.rs:334
+    s.ask("q")
+    s.on_proposal("x")
+    assert not s.ready()                       # no votes yet
+    for i in range(3):
+        s.on_evaluation(i, V.Good, "")
+    assert not s.ready()                       # fan-in incomplete (main.rs:322)
+    assert s.on_evaluation(3, V.Good, "").kind == K.Done
+    assert s.ready()
+    s.reset()
+    assert not s.ready() and s.evaluation_count == 0 and not s.has_answer
+
+
+def test_duplicate_vote_overwrites_like_hashmap_insert():
+    s = core.ConsensusSession(["a", "b"])
+    s.ask("q")
+    s.on_proposal("x")
+    assert s.on_evaluation(0, V.NeedsRefinement, "").kind == K.None_
+    assert s.on_evaluation(0, V.Good, "").kind == K.None_      # same member again: still waiting for b
+    assert s.on_evaluation(1, V.Good, "").kind == K.Done
+
+
+def test_configurable_max_rounds():
+    cfg = core.SessionConfig()
+    cfg.max_rounds = 2
+    s = core.ConsensusSession(NAMES, cfg)
+    assert drive(s, lambda r, i: V.NeedsRefinement) == (1, 8, 2)
+
+
+def test_abstain_does_not_block_unanimity_but_needs_refinement_policy_does():
+    s = core.ConsensusSession(NAMES)
+    s.ask("q"); s.on_proposal("x")
+    for i in range(3):
+        s.on_evaluation(i, V.Good, "")
+    assert s.on_member_failure(3).kind == K.Done and s.ready()
+    cfg = core.SessionConfig()
+    cfg.failure_policy = core.FailurePolicy.NeedsRefinement
+    s = core.ConsensusSession(NAMES, cfg)
+    s.ask("q"); s.on_proposal("x")
+    for i in range(3):
+        s.on_evaluation(i, V.Good, "")
+    a = s.on_member_failure(3)
+    assert a.kind == K.Refine and a.member == 3
+
+
+def test_seeded_choices_are_reproducible_and_roughly_uniform():
+    cfg = core.SessionConfig()
+    cfg.seed = 7
+    picks = [core.ConsensusSession(NAMES, cfg, i).ask("q").member for i in range(400)]
+    picks2 = [core.ConsensusSession(NAMES, cfg, i).ask("q").member for i in range(400)]
+    assert picks == picks2
+    for m in range(4):
+        assert 60 <= picks.count(m) <= 140
+    cfg.proposer_policy = core.ProposerPolicy.RoundRobin
+    assert [core.ConsensusSession(NAMES, cfg, i).ask("q").member for i in range(6)] == [0, 1, 2, 3, 0, 1]
+
+
+@settings(max_examples=200, deadline=None)
+@given(n=st.integers(1, 6), max_rounds=st.integers(1, 7), seed=st.integers(0, 2**32),
+       votes=st.lists(st.sampled_from([V.Good, V.NeedsRefinement, V.Abstain]), min_size=64, max_size=64))
+def test_property_terminates_within_budget(n, max_rounds, seed, votes):
+    cfg = core.SessionConfig()
+    cfg.max_rounds, cfg.seed = max_rounds, seed
+    s = core.ConsensusSession([f"m{i}" for i in range(n)], cfg)
+    n_prop, n_eval, n_ref = drive(s, lambda r, i: votes[(r * 7 + i) % len(votes)])
+    assert n_prop == 1 and n_eval <= max_rounds * n and n_ref <= max_rounds
+    assert s.member_calls == n_prop + n_eval + n_ref <= 1 + max_rounds * n + max_rounds
+    assert s.ready()
+    assert all(v.verdict != V.NeedsRefinement for v in s.transcript[-1].votes) or s.forced
+
+
+# ---------------- end-to-end through Member/Coordinator with a scripted backend ----------------
+
+def make_members(backend, **kw):
+    return [Member(p, backend, **kw) for p in core.default_personas()]
+
+
+def test_coordinator_unanimous_first_round():
+    be = ScriptedBackend({"propose": ["Paris"]})
+    res = Coordinator(make_members(be)).ask("Capital of France?")
+    assert res.answer == "Paris" and res.rounds == 1 and res.member_calls == 5 and res.unanimous
+    roles = [r for r, _ in be.calls]
+    assert roles.count("propose") == 1 and roles.count("evaluate") == 4 and roles.count("refine") == 0
+
+
+def test_coordinator_refines_until_good():
+    evals = iter(["NeedsRefinement\nthin", "Good\nok", "Good\nok", "Good\nok"] + ["Good\nok"] * 4)
+    be = ScriptedBackend({"propose": ["v0"], "evaluate": lambda p: next(evals), "refine": ["v1"]})
+    res = Coordinator(make_members(be)).ask("q")
+    assert res.answer == "v1" and res.rounds == 2 and res.member_calls == 1 + 4 + 1 + 4
+    assert res.transcript[0]["refiner"] == "High Society"
+    # the refiner is not told the evaluators' reasoning (main.rs:56-61)
+    refine_prompt = [p for r, p in be.calls if r == "refine"][0]
+    assert "thin" not in refine_prompt
+
+
+def test_coordinator_round_budget_forces_completion():
+    be = ScriptedBackend({"evaluate": ["NeedsRefinement\nno"], "refine": lambda p: "r"})
+    res = Coordinator(make_members(be)).ask("q")
+    assert res.forced and res.rounds == 5 and res.member_calls == 26 and not res.unanimous
+
+
+def test_malformed_verdict_counts_as_needs_refinement():
+    be = ScriptedBackend({"evaluate": ["Evaluation: Good\nReasoning: x"], "refine": lambda p: "r"})
+    res = Coordinator(make_members(be)).ask("q")
+    assert res.forced            # strict parser rejects the few-shot format (main.rs:149-152)
+    be = ScriptedBackend({"evaluate": ["Evaluation: Good\nReasoning: x"]})
+    res = Coordinator(make_members(be, parse_mode=core.ParseMode.Tolerant)).ask("q")
+    assert res.unanimous and res.rounds == 1
+
+
+def test_fault_injection_dropped_and_garbage_replies():
+    be = ScriptedBackend(fail_every=3, garbage_every=5)
+    results = Coordinator(make_members(be)).ask_many([f"q{i}" for i in range(8)])
+    assert len(results) == 8 and all(r.answer for r in results)
+
+
+def test_many_questions_batched_and_logprob_decisions():
+    be = ScriptedBackend(scores=lambda p, t: [-0.1, -2.0])
+    members = make_members(be, decision_mode="logprob")
+    results = Coordinator(members).ask_many([f"q{i}" for i in range(16)])
+    assert all(r.unanimous and r.rounds == 1 for r in results)
+    assert sum(1 for r, _ in be.calls if r == "score") == 64
+
+
+def test_deadline_returns_current_answer():
+    be = ScriptedBackend({"evaluate": ["NeedsRefinement\nno"], "refine": lambda p: "r"}, delay_s=0.01)
+    res = Coordinator(make_members(be), deadline_s=0.02).ask("q")
+    assert res.forced and res.rounds < 5
+
+
+def test_no_members_is_an_error():
+    with pytest.raises(RuntimeError):
+        Coordinator([]).ask("q")

@@ -1,0 +1,52 @@
+import numpy as np
+from hypothesis import given, settings, strategies as st
+
+from llm_consensus_amd._native import core
+from llm_consensus_amd.consensus import reducers
+
+
+def test_majority_basic_and_ties():
+    r = core.majority_vote(np.array([1, 1, 2, -1], dtype=np.int32), 4)
+    assert (r.winner, r.count, r.valid, r.unanimous) == (1, 2, 3, False) and abs(r.agreement - 2 / 3) < 1e-6
+    r = core.majority_vote(np.array([2, 1, 2, 1], dtype=np.int32), 4, core.TieBreak.LowestClass)
+    assert r.winner == 1
+    r = core.majority_vote(np.array([2, 1, 2, 1], dtype=np.int32), 4, core.TieBreak.FirstVoter)
+    assert r.winner == 2
+    r = core.majority_vote(np.array([-1, -1], dtype=np.int32), 4)
+    assert r.winner == -1 and r.valid == 0
+    r = core.majority_vote(np.array([0, 3, 3], dtype=np.int32), 4, core.TieBreak.LowestClass,
+                           np.array([5.0, 1.0, 1.0], dtype=np.float32))
+    assert r.winner == 0
+
+
+@settings(max_examples=100, deadline=None)
+@given(st.lists(st.lists(st.integers(-1, 3), min_size=5, max_size=5), min_size=1, max_size=8))
+def test_majority_batch_matches_numpy(rows):
+    v = np.array(rows, dtype=np.int32)
+    out = reducers.majority_vote_batch(v, 4)
+    for r in range(v.shape[0]):
+        cnt = np.bincount(v[r][v[r] >= 0], minlength=4)
+        if cnt.sum() == 0:
+            assert out.winner[r] == -1
+        else:
+            assert out.winner[r] == int(np.argmax(cnt)) and out.count[r] == cnt.max()
+            assert out.unanimous[r] == (cnt.max() == cnt.sum())
+
+
+def test_medoid_picks_central_vector():
+    rng = np.random.default_rng(0)
+    base = rng.normal(size=16).astype(np.float32)
+    E = np.stack([base + 0.05 * rng.normal(size=16) for _ in range(5)] + [-base]).astype(np.float32)
+    r = reducers.cosine_medoid(E)
+    assert r.index != 5
+    sims = (E / np.linalg.norm(E, axis=1, keepdims=True)) @ (E / np.linalg.norm(E, axis=1, keepdims=True)).T
+    assert r.index == int(np.argmax(sims.sum(1) - 1))
+    assert abs(r.score - (sims.sum(1)[r.index] - 1) / 5) < 1e-5
+
+
+def test_judge_reduce_and_unanimity():
+    s = np.array([[[0.1, 0.2], [0.9, 0.8], [0.0, 0.95]]], dtype=np.float32)
+    out = reducers.judge_reduce_batch(s)
+    assert out.winner[0] == 1 and not out.unanimous[0]
+    u = reducers.unanimity(np.array([[0, -1], [-2, -1], [0, -3]], dtype=np.float32))
+    assert not u.all_good and u.dissenters == [1]
