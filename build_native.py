@@ -81,7 +81,7 @@ def build_kernels(force: bool = False, jobs: int = 8) -> Path:
     obj_dir = BUILD_DIR / "kernels"
     obj_dir.mkdir(parents=True, exist_ok=True)
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    flags = [f"--offload-arch={GFX_ARCH}", "-O3", "-std=c++17", "-fPIC", "-ffast-math",
+    flags = [f"--offload-arch={GFX_ARCH}", "-O3", "-std=c++17", "-fPIC", "-fno-math-errno", "-ffp-contract=fast",
              "-fno-gpu-rdc", "-Wall", "-Wno-unused-function", f"-I{src_dir}"]
     todo = []
     objs = []

@@ -1,0 +1,430 @@
+// Paged attention for gfx950: prefill (causal, GQA, optional sliding window), decode
+// (one query token per sequence, split-KV), shared-prefix decode (all chains of a
+// sequence group attend to their common prompt blocks in ONE pass, 32 query rows per
+// wave on the MFMA), and the log-sum-exp merge of partial results.
+//
+// KV cache layout (per layer):  K  [num_blocks][Hkv][BS][Dh]   (token-major rows)
+//                               Vt [num_blocks][Hkv][Dh][BS]   (V stored transposed)
+// With V transposed, both MFMA operands of both products are k-contiguous 16-byte
+// loads straight from HBM/L2 into VGPRs: no LDS, no transposing reads.
+//
+// One wave owns 32 query rows. Per 32-key tile it computes S^T = K * Q^T with
+// v_mfma_f32_32x32x16_bf16 (A = K rows, B = Q^T), so the query row lives on the LANE
+// (column) and a lane holds 16 of its 32 scores: softmax needs 15 in-lane ops plus one
+// cross-half shuffle. The 32x32 score tile then feeds O^T += Vt * P^T directly as the
+// B operand of the next MFMA (accumulator registers 8s..8s+7, packed to bf16, are
+// k-step s). MFMA row i of S^T is mapped to key k0 + pi(i), pi = swap bits 2 and 3,
+// which makes the keys of k-step s / lane-half h the contiguous run 16s+8h .. +7 that
+// the Vt fragment load wants.
+//
+// Nothing here has a counterpart in the reference (remote model,
+// /root/reference/src/main.rs:82-86); shared-prefix decode exists because the
+// reference's evaluate prompts and K-chain self-consistency share prompt prefixes.
+#include "common.h"
+
+namespace {
+
+constexpr float kNegBig = -1.0e30f;
+
+struct TileCtx {
+  const bf16_t* __restrict__ Kc;
+  const bf16_t* __restrict__ Vt;
+  const int32_t* __restrict__ bt;  // this sequence's block table
+  int Hkv, kvh, lbs, BS;           // lbs = log2(BS)
+  float scale2;                    // softmax scale * log2(e)
+};
+
+template <int DH>
+struct AttnState {
+  f32x16 o[DH / 32];  // O^T blocks: row d = blk*32 + (reg&3) + 8*(reg>>2) + 4*h, col q = lane&31
+  float m, l;         // running max (log2 domain) and this lane-half's partial sum
+};
+
+// Processes keys [kv_lo, kv_hi) for the wave's 32 rows. Row visibility: lo_q <= key < hi_q.
+template <int DH>
+LC_DEVICE void attend_range(AttnState<DH>& st, const bf16x8 (&qf)[DH / 16], const TileCtx& c, int kv_lo,
+                            int kv_hi, int lo_q, int hi_q, int lane) {
+  const int r = lane & 31, h = lane >> 5;
+  const int pi_r = (r & ~0xC) | ((r & 4) << 1) | ((r & 8) >> 1);
+  const size_t kblk_stride = static_cast<size_t>(c.Hkv) * c.BS * DH;
+  for (int k0 = kv_lo & ~31; k0 < kv_hi; k0 += 32) {
+    // ---- S^T = K * Q^T ----
+    int key = k0 + pi_r;
+    key = key < kv_hi ? key : kv_hi - 1;
+    const bf16_t* kp = c.Kc + static_cast<size_t>(c.bt[key >> c.lbs]) * kblk_stride +
+                       (static_cast<size_t>(c.kvh) * c.BS + (key & (c.BS - 1))) * DH + 8 * h;
+    bf16x8 kf[DH / 16];
+#pragma unroll
+    for (int kk = 0; kk < DH / 16; ++kk) kf[kk] = *reinterpret_cast<const bf16x8*>(kp + 16 * kk);
+    // Vt fragments for this tile: chunk (s, h) = keys k0 + 16s + 8h .. +7
+    bf16x8 vf[DH / 32][2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      int key8 = k0 + 16 * s + 8 * h;
+      const int last8 = (kv_hi - 1) & ~7;
+      key8 = key8 < kv_hi ? key8 : last8;
+      const bf16_t* vp = c.Vt + static_cast<size_t>(c.bt[key8 >> c.lbs]) * kblk_stride +
+                         (static_cast<size_t>(c.kvh) * DH + r) * c.BS + (key8 & (c.BS - 1));
+#pragma unroll
+      for (int b = 0; b < DH / 32; ++b)
+        vf[b][s] = *reinterpret_cast<const bf16x8*>(vp + static_cast<size_t>(b) * 32 * c.BS);
+    }
+    f32x16 sc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kk = 0; kk < DH / 16; ++kk)
+      sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[kk], qf[kk], sc, 0, 0, 0);
+
+    // ---- online softmax (row q = lane&31; this lane holds keys k0 + 16*(reg>>3) + 8h + (reg&7)) ----
+    float tmax = kNegBig;
+    bool vis[16];
+#pragma unroll
+    for (int g = 0; g < 16; ++g) {
+      const int kidx = k0 + 16 * (g >> 3) + 8 * h + (g & 7);
+      vis[g] = (kidx >= lo_q) && (kidx < hi_q);
+      sc[g] = vis[g] ? sc[g] * c.scale2 : kNegBig;
+      tmax = fmaxf(tmax, sc[g]);
+    }
+    tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+    const float m_new = fmaxf(st.m, tmax);
+    const float alpha = exp2f(st.m - m_new);
+    st.m = m_new;
+    float psum = 0.f;
+#pragma unroll
+    for (int g = 0; g < 16; ++g) {
+      const float p = vis[g] ? exp2f(sc[g] - m_new) : 0.f;
+      sc[g] = p;
+      psum += p;
+    }
+    st.l = st.l * alpha + psum;
+#pragma unroll
+    for (int b = 0; b < DH / 32; ++b)
+#pragma unroll
+      for (int g = 0; g < 16; ++g) st.o[b][g] *= alpha;
+
+    // ---- O^T += Vt * P^T ----
+    bf16x8 pf[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      u32x4 packed;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) packed[j] = pack_bf16x2(sc[8 * s + 2 * j], sc[8 * s + 2 * j + 1]);
+      pf[s] = __builtin_bit_cast(bf16x8, packed);
+    }
+#pragma unroll
+    for (int b = 0; b < DH / 32; ++b)
+#pragma unroll
+      for (int s = 0; s < 2; ++s)
+        st.o[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[b][s], pf[s], st.o[b], 0, 0, 0);
+  }
+}
+
+template <int DH>
+LC_DEVICE void init_state(AttnState<DH>& st) {
+#pragma unroll
+  for (int b = 0; b < DH / 32; ++b)
+#pragma unroll
+    for (int g = 0; g < 16; ++g) st.o[b][g] = 0.f;
+  st.m = kNegBig;
+  st.l = 0.f;
+}
+
+template <int DH>
+LC_DEVICE void load_q(bf16x8 (&qf)[DH / 16], const bf16_t* qrow, int lane) {
+  const int h = lane >> 5;
+#pragma unroll
+  for (int kk = 0; kk < DH / 16; ++kk) {
+    if (qrow) qf[kk] = *reinterpret_cast<const bf16x8*>(qrow + 16 * kk + 8 * h);
+    else qf[kk] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+  }
+}
+
+// Final normalisation + store. bf16 rows (final output) or fp32 rows + lse2 (partials).
+template <int DH>
+LC_DEVICE void finish_and_store(AttnState<DH>& st, bf16_t* out_bf16, float* out_f32, float* out_lse,
+                                int lane) {
+  const int h = lane >> 5;
+  const float l = st.l + __shfl_xor(st.l, 32, 64);
+  const float inv = l > 0.f ? 1.f / l : 0.f;
+  if (out_lse && h == 0) *out_lse = l > 0.f ? st.m + log2f(l) : kNegBig;
+#pragma unroll
+  for (int b = 0; b < DH / 32; ++b)
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4) {
+      const int d = b * 32 + 8 * g4 + 4 * h;
+      const float v0 = st.o[b][4 * g4 + 0] * inv, v1 = st.o[b][4 * g4 + 1] * inv;
+      const float v2 = st.o[b][4 * g4 + 2] * inv, v3 = st.o[b][4 * g4 + 3] * inv;
+      if (out_bf16) {
+        u32x2 o;
+        o[0] = pack_bf16x2(v0, v1);
+        o[1] = pack_bf16x2(v2, v3);
+        *reinterpret_cast<u32x2*>(out_bf16 + d) = o;
+      } else if (out_f32) {
+        *reinterpret_cast<f32x4*>(out_f32 + d) = f32x4{v0, v1, v2, v3};
+      }
+    }
+}
+
+// ------------------------------------------------------------------ prefill
+// grid (q_tile, kv_head, seq); block = G waves (G = Hq/Hkv), wave g = q-head kvh*G+g.
+template <int DH>
+__global__ void attn_prefill_kernel(const bf16_t* __restrict__ Q, int q_stride,
+                                    const bf16_t* __restrict__ Kc, const bf16_t* __restrict__ Vt,
+                                    const int32_t* __restrict__ block_tables, int max_blocks,
+                                    const int32_t* __restrict__ cu_q, const int32_t* __restrict__ ctx_lens,
+                                    bf16_t* __restrict__ out, int Hq, int Hkv, int lbs, float scale2,
+                                    int window) {
+  const int s = blockIdx.z, kvh = blockIdx.y, tile = blockIdx.x;
+  const int q0 = cu_q[s], q_len = cu_q[s + 1] - q0;
+  if (tile * 32 >= q_len) return;
+  const int lane = threadIdx.x & 63;
+  const int g = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int G = Hq / Hkv;
+  const int head = kvh * G + g;
+  const int ctx = ctx_lens[s];
+  const int base_pos = ctx - q_len;
+  const int i = tile * 32 + (lane & 31);
+  const bool valid = i < q_len;
+  const int pos = base_pos + i;
+  const int hi_q = valid ? pos + 1 : 0;
+  const int lo_q = (valid && window > 0 && pos + 1 > window) ? pos + 1 - window : 0;
+
+  bf16x8 qf[DH / 16];
+  load_q<DH>(qf, valid ? Q + static_cast<size_t>(q0 + i) * q_stride + head * DH : nullptr, lane);
+  TileCtx c{Kc, Vt, block_tables + static_cast<size_t>(s) * max_blocks, Hkv, kvh, lbs, 1 << lbs, scale2};
+  AttnState<DH> st;
+  init_state<DH>(st);
+  const int last_row = min(tile * 32 + 31, q_len - 1);
+  const int kv_hi = base_pos + last_row + 1;
+  int kv_lo = 0;
+  if (window > 0) {
+    const int first_pos = base_pos + tile * 32;
+    kv_lo = first_pos + 1 > window ? first_pos + 1 - window : 0;
+  }
+  attend_range<DH>(st, qf, c, kv_lo, kv_hi, lo_q, hi_q, lane);
+  bf16_t* orow = valid ? out + static_cast<size_t>(q0 + i) * (Hq * DH) + head * DH : nullptr;
+  finish_and_store<DH>(st, orow, nullptr, nullptr, lane);
+}
+
+// ------------------------------------------------------------------ decode
+// One query token per sequence. grid (kv_head, seq, split); block = 1 wave; MFMA columns
+// 0..G-1 carry the G query heads of this kv head. Keys [kv_begin[b], ctx_len[b]) are cut
+// into `nsplit` ranges. With partials == nullptr (nsplit == 1) the bf16 output is final.
+template <int DH>
+__global__ void attn_decode_kernel(const bf16_t* __restrict__ Q, int q_stride,
+                                   const bf16_t* __restrict__ Kc, const bf16_t* __restrict__ Vt,
+                                   const int32_t* __restrict__ block_tables, int max_blocks,
+                                   const int32_t* __restrict__ ctx_lens, const int32_t* __restrict__ kv_begin,
+                                   bf16_t* __restrict__ out, float* __restrict__ part_o,
+                                   float* __restrict__ part_lse, int np_total, int Hq, int Hkv, int lbs,
+                                   float scale2, int window) {
+  const int kvh = blockIdx.x, b = blockIdx.y, split = blockIdx.z, nsplit = gridDim.z;
+  const int lane = threadIdx.x & 63;
+  const int G = Hq / Hkv;
+  const int q = lane & 31;
+  const bool valid = q < G;
+  const int head = kvh * G + q;
+  const int ctx = ctx_lens[b];
+  int begin = kv_begin ? kv_begin[b] : 0;
+  if (window > 0 && ctx > window) begin = max(begin, ctx - window);
+  // split the range on 32-key boundaries
+  const int ntile = (ctx - (begin & ~31) + 31) / 32;
+  const int per = (ntile + nsplit - 1) / nsplit;
+  const int lo = max(begin, (begin & ~31) + split * per * 32);
+  const int hi = min(ctx, (begin & ~31) + (split + 1) * per * 32);
+
+  bf16x8 qf[DH / 16];
+  load_q<DH>(qf, valid ? Q + static_cast<size_t>(b) * q_stride + head * DH : nullptr, lane);
+  TileCtx c{Kc, Vt, block_tables + static_cast<size_t>(b) * max_blocks, Hkv, kvh, lbs, 1 << lbs, scale2};
+  AttnState<DH> st;
+  init_state<DH>(st);
+  if (lo < hi) attend_range<DH>(st, qf, c, lo, hi, valid ? lo : 0, valid ? hi : 0, lane);
+  if (part_o) {
+    const size_t slot = (static_cast<size_t>(b) * Hq + head) * np_total + split;
+    finish_and_store<DH>(st, nullptr, valid ? part_o + slot * DH : nullptr, valid ? part_lse + slot : nullptr,
+                         lane);
+  } else {
+    finish_and_store<DH>(st, valid ? out + static_cast<size_t>(b) * (Hq * DH) + head * DH : nullptr, nullptr,
+                         nullptr, lane);
+  }
+}
+
+// ------------------------------------------------------------------ shared-prefix decode
+// Group g = `count` consecutive batch rows starting at `first` whose first
+// `shared_blocks` KV blocks are identical. Rows of the MFMA tile = (chain, q-head in the
+// kv head's GQA group): count*G rows, 32 per wave. Every row sees every prefix key, so
+// the prefix K/V is read once per kv head for the whole group instead of once per chain.
+// grid (row_tile, kv_head, group*nsplit + split); block = 1 wave. Writes partial slots
+// [slot0 + split].
+template <int DH>
+__global__ void attn_prefix_kernel(const bf16_t* __restrict__ Q, int q_stride,
+                                   const bf16_t* __restrict__ Kc, const bf16_t* __restrict__ Vt,
+                                   const int32_t* __restrict__ block_tables, int max_blocks,
+                                   const int32_t* __restrict__ group_first,
+                                   const int32_t* __restrict__ group_count,
+                                   const int32_t* __restrict__ group_shared_blocks, int nsplit,
+                                   float* __restrict__ part_o, float* __restrict__ part_lse, int np_total,
+                                   int slot0, int Hq, int Hkv, int lbs, float scale2) {
+  const int grp = blockIdx.z / nsplit, split = blockIdx.z % nsplit;
+  const int kvh = blockIdx.y;
+  const int lane = threadIdx.x & 63;
+  const int G = Hq / Hkv;
+  const int first = group_first[grp], count = group_count[grp];
+  const int plen = group_shared_blocks[grp] << lbs;
+  const int row = blockIdx.x * 32 + (lane & 31);
+  if (blockIdx.x * 32 >= count * G) return;
+  const bool valid = row < count * G;
+  const int chain = row / G, qh = row % G;
+  const int b = first + chain;
+  const int head = kvh * G + qh;
+  const int ntile = plen / 32;  // BS >= 32 keeps plen a multiple of 32; smaller BS handled by masking
+  const int per = ((plen + 31) / 32 + nsplit - 1) / nsplit;
+  const int lo = split * per * 32;
+  const int hi = min(plen, (split + 1) * per * 32);
+  (void)ntile;
+
+  bf16x8 qf[DH / 16];
+  load_q<DH>(qf, valid ? Q + static_cast<size_t>(b) * q_stride + head * DH : nullptr, lane);
+  TileCtx c{Kc, Vt, block_tables + static_cast<size_t>(first) * max_blocks, Hkv, kvh, lbs, 1 << lbs, scale2};
+  AttnState<DH> st;
+  init_state<DH>(st);
+  if (lo < hi) attend_range<DH>(st, qf, c, lo, hi, valid ? lo : 0, valid ? hi : 0, lane);
+  const size_t slot = valid ? (static_cast<size_t>(b) * Hq + head) * np_total + slot0 + split : 0;
+  finish_and_store<DH>(st, nullptr, valid ? part_o + slot * DH : nullptr, valid ? part_lse + slot : nullptr, lane);
+}
+
+// ------------------------------------------------------------------ merge
+// out[b, head, :] = sum_p w_p * part_o[b, head, p, :],  w_p = 2^(lse_p - max) / sum.
+// One wave per (b, head); lanes cover Dh.
+template <int DH>
+__global__ void attn_merge_kernel(const float* __restrict__ part_o, const float* __restrict__ part_lse,
+                                  bf16_t* __restrict__ out, int np_total, int n_rows) {
+  const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= n_rows) return;
+  const float* lse = part_lse + static_cast<size_t>(row) * np_total;
+  float mx = kNegBig;
+  for (int p = 0; p < np_total; ++p) mx = fmaxf(mx, lse[p]);
+  float acc[DH / 64] = {0.f};
+  float wsum = 0.f;
+  for (int p = 0; p < np_total; ++p) {
+    const float l = lse[p];
+    if (l <= kNegBig * 0.5f) continue;
+    const float w = exp2f(l - mx);
+    wsum += w;
+    const float* o = part_o + (static_cast<size_t>(row) * np_total + p) * DH;
+#pragma unroll
+    for (int i = 0; i < DH / 64; ++i) acc[i] += w * o[lane + 64 * i];
+  }
+  const float inv = wsum > 0.f ? 1.f / wsum : 0.f;
+#pragma unroll
+  for (int i = 0; i < DH / 64; ++i)
+    out[static_cast<size_t>(row) * DH + lane + 64 * i] = f32_to_bf16(acc[i] * inv);
+}
+
+__global__ void fill_f32_kernel(float* __restrict__ p, float v, size_t n) {
+  for (size_t i = blockIdx.x * static_cast<size_t>(blockDim.x) + threadIdx.x; i < n;
+       i += static_cast<size_t>(gridDim.x) * blockDim.x)
+    p[i] = v;
+}
+
+int ilog2(int x) {
+  int l = 0;
+  while ((1 << l) < x) ++l;
+  return l;
+}
+
+}  // namespace
+
+LC_EXPORT int lc_attn_prefill(const void* Q, int q_stride, const void* Kc, const void* Vt,
+                              const void* block_tables, int max_blocks, const void* cu_q,
+                              const void* ctx_lens, void* out, int n_seqs, int max_q_len, int Hq, int Hkv,
+                              int Dh, int block_size, float scale, int window, hipStream_t stream) {
+  if (n_seqs <= 0 || max_q_len <= 0) return 0;
+  if (Hq % Hkv || Hq / Hkv > 16 || (Dh != 64 && Dh != 128) || block_size % 8 ||
+      (block_size & (block_size - 1)))
+    return -1;
+  const dim3 grid((max_q_len + 31) / 32, Hkv, n_seqs), block(64 * (Hq / Hkv));
+  const float scale2 = scale * 1.4426950408889634f;
+  const int lbs = ilog2(block_size);
+#define LC_ARGS                                                                                          \
+  static_cast<const bf16_t*>(Q), q_stride, static_cast<const bf16_t*>(Kc), static_cast<const bf16_t*>(Vt), \
+      static_cast<const int32_t*>(block_tables), max_blocks, static_cast<const int32_t*>(cu_q),          \
+      static_cast<const int32_t*>(ctx_lens), static_cast<bf16_t*>(out), Hq, Hkv, lbs, scale2, window
+  if (Dh == 128) attn_prefill_kernel<128><<<grid, block, 0, stream>>>(LC_ARGS);
+  else attn_prefill_kernel<64><<<grid, block, 0, stream>>>(LC_ARGS);
+#undef LC_ARGS
+  LC_RETURN_LAST_ERROR();
+}
+
+// Decode attention. part_o/part_lse may be null when nsplit == 1 and no prefix pass is
+// used; otherwise partial slot `split` of np_total is written and lc_attn_merge finishes.
+LC_EXPORT int lc_attn_decode(const void* Q, int q_stride, const void* Kc, const void* Vt,
+                             const void* block_tables, int max_blocks, const void* ctx_lens,
+                             const void* kv_begin, void* out, void* part_o, void* part_lse, int np_total,
+                             int nsplit, int n_seqs, int Hq, int Hkv, int Dh, int block_size, float scale,
+                             int window, hipStream_t stream) {
+  if (n_seqs <= 0) return 0;
+  if (Hq % Hkv || Hq / Hkv > 32 || (Dh != 64 && Dh != 128) || block_size % 8 ||
+      (block_size & (block_size - 1)) || nsplit < 1 || (!part_o && nsplit != 1) || nsplit > np_total)
+    return -1;
+  const dim3 grid(Hkv, n_seqs, nsplit), block(64);
+  const float scale2 = scale * 1.4426950408889634f;
+  const int lbs = ilog2(block_size);
+#define LC_ARGS                                                                                          \
+  static_cast<const bf16_t*>(Q), q_stride, static_cast<const bf16_t*>(Kc), static_cast<const bf16_t*>(Vt), \
+      static_cast<const int32_t*>(block_tables), max_blocks, static_cast<const int32_t*>(ctx_lens),      \
+      static_cast<const int32_t*>(kv_begin), static_cast<bf16_t*>(out), static_cast<float*>(part_o),     \
+      static_cast<float*>(part_lse), np_total, Hq, Hkv, lbs, scale2, window
+  if (Dh == 128) attn_decode_kernel<128><<<grid, block, 0, stream>>>(LC_ARGS);
+  else attn_decode_kernel<64><<<grid, block, 0, stream>>>(LC_ARGS);
+#undef LC_ARGS
+  LC_RETURN_LAST_ERROR();
+}
+
+LC_EXPORT int lc_attn_prefix(const void* Q, int q_stride, const void* Kc, const void* Vt,
+                             const void* block_tables, int max_blocks, const void* group_first,
+                             const void* group_count, const void* group_shared_blocks, int n_groups,
+                             int max_group_rows, int nsplit, void* part_o, void* part_lse, int np_total,
+                             int slot0, int Hq, int Hkv, int Dh, int block_size, float scale,
+                             hipStream_t stream) {
+  if (n_groups <= 0 || max_group_rows <= 0) return 0;
+  if (Hq % Hkv || (Dh != 64 && Dh != 128) || block_size % 8 || (block_size & (block_size - 1)) ||
+      nsplit < 1 || slot0 + nsplit > np_total)
+    return -1;
+  const int G = Hq / Hkv;
+  const dim3 grid((max_group_rows * G + 31) / 32, Hkv, n_groups * nsplit), block(64);
+  const float scale2 = scale * 1.4426950408889634f;
+  const int lbs = ilog2(block_size);
+#define LC_ARGS                                                                                          \
+  static_cast<const bf16_t*>(Q), q_stride, static_cast<const bf16_t*>(Kc), static_cast<const bf16_t*>(Vt), \
+      static_cast<const int32_t*>(block_tables), max_blocks, static_cast<const int32_t*>(group_first),   \
+      static_cast<const int32_t*>(group_count), static_cast<const int32_t*>(group_shared_blocks), nsplit, \
+      static_cast<float*>(part_o), static_cast<float*>(part_lse), np_total, slot0, Hq, Hkv, lbs, scale2
+  if (Dh == 128) attn_prefix_kernel<128><<<grid, block, 0, stream>>>(LC_ARGS);
+  else attn_prefix_kernel<64><<<grid, block, 0, stream>>>(LC_ARGS);
+#undef LC_ARGS
+  LC_RETURN_LAST_ERROR();
+}
+
+LC_EXPORT int lc_attn_merge(const void* part_o, const void* part_lse, void* out, int np_total, int n_rows,
+                            int Dh, hipStream_t stream) {
+  if (n_rows <= 0) return 0;
+  if (Dh != 64 && Dh != 128) return -1;
+  const dim3 grid((n_rows + 3) / 4), block(256);
+  if (Dh == 128)
+    attn_merge_kernel<128><<<grid, block, 0, stream>>>(static_cast<const float*>(part_o),
+                                                       static_cast<const float*>(part_lse),
+                                                       static_cast<bf16_t*>(out), np_total, n_rows);
+  else
+    attn_merge_kernel<64><<<grid, block, 0, stream>>>(static_cast<const float*>(part_o),
+                                                      static_cast<const float*>(part_lse),
+                                                      static_cast<bf16_t*>(out), np_total, n_rows);
+  LC_RETURN_LAST_ERROR();
+}
+
+LC_EXPORT int lc_fill_f32(void* p, float v, long long n, hipStream_t stream) {
+  if (n <= 0) return 0;
+  const int grid = static_cast<int>(std::min<long long>((n + 255) / 256, 2048));
+  fill_f32_kernel<<<dim3(grid), dim3(256), 0, stream>>>(static_cast<float*>(p), v, static_cast<size_t>(n));
+  LC_RETURN_LAST_ERROR();
+}

@@ -1,0 +1,212 @@
+// Memory-bound row kernels: embedding gather, RMSNorm (+ fused residual add), SwiGLU,
+// KV block copy, embedding pooling. All use 16-byte per-lane accesses and one wave per
+// row; none of them exists in the reference (its model is remote,
+// /root/reference/src/main.rs:82-86).
+#include "common.h"
+
+namespace {
+
+constexpr int kMaxChunksPerLane = 16;  // rows up to 16*64*8 = 8192 elements stay in registers
+
+// x[t,:] = E[ids[t],:]
+__global__ void embed_gather_kernel(const int32_t* __restrict__ ids, const bf16_t* __restrict__ E,
+                                    bf16_t* __restrict__ x, int T, int d, int vocab) {
+  const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= T) return;
+  int id = ids[row];
+  id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
+  const u32x4* src = reinterpret_cast<const u32x4*>(E + static_cast<size_t>(id) * d);
+  u32x4* dst = reinterpret_cast<u32x4*>(x + static_cast<size_t>(row) * d);
+  for (int c = lane; c < d / 8; c += 64) dst[c] = src[c];
+}
+
+// If `delta` != nullptr: h += delta (h is the bf16 residual stream, updated in place),
+// then y = h * rsqrt(mean(h^2) + eps) * w. With delta == nullptr it is a plain RMSNorm of h.
+__global__ void rmsnorm_kernel(bf16_t* __restrict__ h, const bf16_t* __restrict__ delta,
+                               const bf16_t* __restrict__ w, bf16_t* __restrict__ y, int T, int d,
+                               float eps) {
+  const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= T) return;
+  const int nchunk = d / 8;
+  bf16_t* hrow = h + static_cast<size_t>(row) * d;
+  const bf16_t* drow = delta ? delta + static_cast<size_t>(row) * d : nullptr;
+  float v[kMaxChunksPerLane][8];
+  float ss = 0.f;
+#pragma unroll
+  for (int i = 0; i < kMaxChunksPerLane; ++i) {
+    const int c = lane + i * 64;
+    if (c < nchunk) {
+      bf16x8 a = *reinterpret_cast<const bf16x8*>(hrow + c * 8);
+      if (drow) {
+        bf16x8 b = *reinterpret_cast<const bf16x8*>(drow + c * 8);
+        bf16x8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          float s = bf16_to_f32(static_cast<bf16_t>(a[j])) + bf16_to_f32(static_cast<bf16_t>(b[j]));
+          bf16_t r = f32_to_bf16(s);
+          o[j] = static_cast<short>(r);
+          v[i][j] = bf16_to_f32(r);  // normalise exactly what the residual stream now holds
+        }
+        *reinterpret_cast<bf16x8*>(hrow + c * 8) = o;
+      } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[i][j] = bf16_to_f32(static_cast<bf16_t>(a[j]));
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) ss += v[i][j] * v[i][j];
+    }
+  }
+  ss = wave_sum(ss);
+  const float scale = rsqrtf(ss / static_cast<float>(d) + eps);
+  bf16_t* yrow = y + static_cast<size_t>(row) * d;
+#pragma unroll
+  for (int i = 0; i < kMaxChunksPerLane; ++i) {
+    const int c = lane + i * 64;
+    if (c < nchunk) {
+      bf16x8 g = *reinterpret_cast<const bf16x8*>(w + c * 8);
+      bf16x8 o;
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        o[j] = static_cast<short>(f32_to_bf16(v[i][j] * scale * bf16_to_f32(static_cast<bf16_t>(g[j]))));
+      *reinterpret_cast<bf16x8*>(yrow + c * 8) = o;
+    }
+  }
+}
+
+// act[t, i] = silu(gu[t, i]) * gu[t, dff + i]   (gate and up halves stored side by side)
+__global__ void swiglu_kernel(const bf16_t* __restrict__ gu, bf16_t* __restrict__ act, int T, int dff) {
+  const size_t nchunk = static_cast<size_t>(T) * (dff / 8);
+  for (size_t c = blockIdx.x * static_cast<size_t>(blockDim.x) + threadIdx.x; c < nchunk;
+       c += static_cast<size_t>(gridDim.x) * blockDim.x) {
+    const size_t t = c / (dff / 8), i = c % (dff / 8);
+    const bf16_t* g = gu + t * (2 * static_cast<size_t>(dff)) + i * 8;
+    bf16x8 a = *reinterpret_cast<const bf16x8*>(g);
+    bf16x8 b = *reinterpret_cast<const bf16x8*>(g + dff);
+    bf16x8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float x = bf16_to_f32(static_cast<bf16_t>(a[j]));
+      const float u = bf16_to_f32(static_cast<bf16_t>(b[j]));
+      o[j] = static_cast<short>(f32_to_bf16(x / (1.f + __expf(-x)) * u));
+    }
+    *reinterpret_cast<bf16x8*>(act + t * static_cast<size_t>(dff) + i * 8) = o;
+  }
+}
+
+// y = a + b (bf16), used for residual adds outside the fused norm.
+__global__ void add_kernel(const bf16_t* __restrict__ a, const bf16_t* __restrict__ b,
+                           bf16_t* __restrict__ y, size_t nchunk) {
+  for (size_t c = blockIdx.x * static_cast<size_t>(blockDim.x) + threadIdx.x; c < nchunk;
+       c += static_cast<size_t>(gridDim.x) * blockDim.x) {
+    bf16x8 x = reinterpret_cast<const bf16x8*>(a)[c];
+    bf16x8 z = reinterpret_cast<const bf16x8*>(b)[c];
+    bf16x8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      o[j] = static_cast<short>(
+          f32_to_bf16(bf16_to_f32(static_cast<bf16_t>(x[j])) + bf16_to_f32(static_cast<bf16_t>(z[j]))));
+    reinterpret_cast<bf16x8*>(y)[c] = o;
+  }
+}
+
+// Copy-on-write of KV blocks: for every (src, dst) pair copy `block_bytes` bytes in each
+// of the `n_planes` cache planes (planes are `plane_stride` bytes apart).
+__global__ void copy_blocks_kernel(char* __restrict__ base, const int32_t* __restrict__ src,
+                                   const int32_t* __restrict__ dst, size_t block_bytes,
+                                   size_t plane_stride) {
+  const int pair = blockIdx.x;
+  const size_t plane = blockIdx.y;
+  const u32x4* s = reinterpret_cast<const u32x4*>(base + plane * plane_stride + src[pair] * block_bytes);
+  u32x4* d = reinterpret_cast<u32x4*>(base + plane * plane_stride + dst[pair] * block_bytes);
+  for (size_t i = threadIdx.x; i < block_bytes / 16; i += blockDim.x) d[i] = s[i];
+}
+
+// Pooled, L2-normalised sentence embedding. One block per sequence.
+// mode 0: mean over the sequence's rows [cu[s], cu[s+1]); mode 1: last row only.
+__global__ void embed_pool_kernel(const bf16_t* __restrict__ hidden, const int32_t* __restrict__ cu,
+                                  float* __restrict__ out, int d, int mode) {
+  __shared__ float red[16];
+  const int s = blockIdx.x;
+  const int r0 = cu[s], r1 = cu[s + 1];
+  const int n = r1 - r0;
+  float ss = 0.f;
+  for (int c = threadIdx.x; c < d; c += blockDim.x) {
+    float acc = 0.f;
+    if (n > 0) {
+      if (mode == 1) {
+        acc = bf16_to_f32(hidden[static_cast<size_t>(r1 - 1) * d + c]);
+      } else {
+        for (int r = r0; r < r1; ++r) acc += bf16_to_f32(hidden[static_cast<size_t>(r) * d + c]);
+        acc /= static_cast<float>(n);
+      }
+    }
+    out[static_cast<size_t>(s) * d + c] = acc;
+    ss += acc * acc;
+  }
+  ss = block_sum(ss, red);
+  const float inv = ss > 0.f ? rsqrtf(ss) : 0.f;
+  for (int c = threadIdx.x; c < d; c += blockDim.x) out[static_cast<size_t>(s) * d + c] *= inv;
+}
+
+}  // namespace
+
+LC_EXPORT int lc_embed_gather(const void* ids, const void* E, void* x, int T, int d, int vocab,
+                              hipStream_t stream) {
+  if (T <= 0) return 0;
+  if (d % 8) return -1;
+  embed_gather_kernel<<<dim3((T + 3) / 4), dim3(256), 0, stream>>>(
+      static_cast<const int32_t*>(ids), static_cast<const bf16_t*>(E), static_cast<bf16_t*>(x), T, d, vocab);
+  LC_RETURN_LAST_ERROR();
+}
+
+LC_EXPORT int lc_rmsnorm(void* h, const void* delta, const void* w, void* y, int T, int d, float eps,
+                         hipStream_t stream) {
+  if (T <= 0) return 0;
+  if (d % 8 || d > kMaxChunksPerLane * 64 * 8) return -1;
+  rmsnorm_kernel<<<dim3((T + 3) / 4), dim3(256), 0, stream>>>(
+      static_cast<bf16_t*>(h), static_cast<const bf16_t*>(delta), static_cast<const bf16_t*>(w),
+      static_cast<bf16_t*>(y), T, d, eps);
+  LC_RETURN_LAST_ERROR();
+}
+
+LC_EXPORT int lc_swiglu(const void* gu, void* act, int T, int dff, hipStream_t stream) {
+  if (T <= 0) return 0;
+  if (dff % 8) return -1;
+  const size_t nchunk = static_cast<size_t>(T) * (dff / 8);
+  const int grid = static_cast<int>(std::min<size_t>((nchunk + 255) / 256, 4096));
+  swiglu_kernel<<<dim3(grid), dim3(256), 0, stream>>>(static_cast<const bf16_t*>(gu),
+                                                      static_cast<bf16_t*>(act), T, dff);
+  LC_RETURN_LAST_ERROR();
+}
+
+LC_EXPORT int lc_add(const void* a, const void* b, void* y, long long n, hipStream_t stream) {
+  if (n <= 0) return 0;
+  if (n % 8) return -1;
+  const size_t nchunk = static_cast<size_t>(n) / 8;
+  const int grid = static_cast<int>(std::min<size_t>((nchunk + 255) / 256, 4096));
+  add_kernel<<<dim3(grid), dim3(256), 0, stream>>>(static_cast<const bf16_t*>(a),
+                                                   static_cast<const bf16_t*>(b),
+                                                   static_cast<bf16_t*>(y), nchunk);
+  LC_RETURN_LAST_ERROR();
+}
+
+LC_EXPORT int lc_copy_blocks(void* base, const void* src, const void* dst, int n_pairs,
+                             long long block_bytes, long long plane_stride, int n_planes,
+                             hipStream_t stream) {
+  if (n_pairs <= 0) return 0;
+  if (block_bytes % 16) return -1;
+  copy_blocks_kernel<<<dim3(n_pairs, n_planes), dim3(256), 0, stream>>>(
+      static_cast<char*>(base), static_cast<const int32_t*>(src), static_cast<const int32_t*>(dst),
+      static_cast<size_t>(block_bytes), static_cast<size_t>(plane_stride));
+  LC_RETURN_LAST_ERROR();
+}
+
+LC_EXPORT int lc_embed_pool(const void* hidden, const void* cu, void* out, int n_seqs, int d, int mode,
+                            hipStream_t stream) {
+  if (n_seqs <= 0) return 0;
+  embed_pool_kernel<<<dim3(n_seqs), dim3(256), 0, stream>>>(
+      static_cast<const bf16_t*>(hidden), static_cast<const int32_t*>(cu), static_cast<float*>(out), d, mode);
+  LC_RETURN_LAST_ERROR();
+}

@@ -1,0 +1,201 @@
+// Mixture-of-experts routing for Mixtral-style layers: router logits + softmax + top-k,
+// permutation of token rows into expert order (histogram + prefix sum in LDS), and the
+// weighted combine of expert outputs. The expert FFN itself is lc_gemm_grouped (gemm.hip),
+// which gathers rows through the permutation, so no permuted activation copy is written.
+// No counterpart in the reference (remote model, /root/reference/src/main.rs:82-86).
+#include "common.h"
+
+namespace {
+
+constexpr int kMaxExperts = 16;
+constexpr int kMaxTopK = 4;
+
+// One wave per token: logits[e] = x . Wr[e], softmax over experts, top-k, renormalise.
+__global__ void moe_router_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ Wr, int T,
+                                  int d, int E, int topk, int32_t* __restrict__ topk_ids,
+                                  float* __restrict__ topk_w, float* __restrict__ router_logits) {
+  const int t = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (t >= T) return;
+  float acc[kMaxExperts];
+#pragma unroll
+  for (int e = 0; e < kMaxExperts; ++e) acc[e] = 0.f;
+  const bf16_t* xr = x + static_cast<size_t>(t) * d;
+  for (int c = lane; c < d / 8; c += 64) {
+    const bf16x8 xv = *reinterpret_cast<const bf16x8*>(xr + c * 8);
+    float xf[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) xf[j] = bf16_to_f32(static_cast<bf16_t>(xv[j]));
+#pragma unroll
+    for (int e = 0; e < kMaxExperts; ++e) {
+      if (e < E) {
+        const bf16x8 wv = *reinterpret_cast<const bf16x8*>(Wr + static_cast<size_t>(e) * d + c * 8);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[e] += xf[j] * bf16_to_f32(static_cast<bf16_t>(wv[j]));
+      }
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < kMaxExperts; ++e) acc[e] = wave_sum(acc[e]);
+  if (lane == 0) {
+    // HF Mixtral rounds router logits to the activation dtype before the softmax.
+    float mx = -INFINITY;
+    for (int e = 0; e < E; ++e) {
+      acc[e] = bf16_to_f32(f32_to_bf16(acc[e]));
+      if (router_logits) router_logits[static_cast<size_t>(t) * E + e] = acc[e];
+      mx = fmaxf(mx, acc[e]);
+    }
+    float p[kMaxExperts], sum = 0.f;
+    for (int e = 0; e < E; ++e) {
+      p[e] = __expf(acc[e] - mx);
+      sum += p[e];
+    }
+    int ids[kMaxTopK];
+    float w[kMaxTopK], wsum = 0.f;
+    for (int k = 0; k < topk; ++k) {
+      int best = -1;
+      for (int e = 0; e < E; ++e) {
+        bool used = false;
+        for (int j = 0; j < k; ++j) used |= ids[j] == e;
+        if (!used && (best < 0 || p[e] > p[best])) best = e;
+      }
+      ids[k] = best;
+      w[k] = p[best] / sum;
+      wsum += w[k];
+    }
+    for (int k = 0; k < topk; ++k) {
+      topk_ids[static_cast<size_t>(t) * topk + k] = ids[k];
+      topk_w[static_cast<size_t>(t) * topk + k] = w[k] / wsum;
+    }
+  }
+}
+
+// Single block. Builds offsets[E+1] (rows per expert, prefix-summed), sorted_src[slot] =
+// source token row, and slot_of[t*topk+k] = slot, for A = T*topk assignments.
+__global__ __launch_bounds__(1024) void moe_permute_kernel(const int32_t* __restrict__ topk_ids, int A,
+                                                           int topk, int E, int32_t* __restrict__ offsets,
+                                                           int32_t* __restrict__ sorted_src,
+                                                           int32_t* __restrict__ slot_of) {
+  __shared__ int counts[kMaxExperts];
+  __shared__ int base[kMaxExperts + 1];
+  __shared__ int cursor[kMaxExperts];
+  if (threadIdx.x < kMaxExperts) {
+    counts[threadIdx.x] = 0;
+    cursor[threadIdx.x] = 0;
+  }
+  __syncthreads();
+  for (int a = threadIdx.x; a < A; a += blockDim.x) atomicAdd(&counts[topk_ids[a]], 1);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int run = 0;
+    for (int e = 0; e < E; ++e) {
+      base[e] = run;
+      offsets[e] = run;
+      run += counts[e];
+    }
+    base[E] = run;
+    offsets[E] = run;
+  }
+  __syncthreads();
+  // Deterministic placement: assignment a goes after all assignments a' < a of the same
+  // expert. Each thread handles a contiguous chunk; chunk-level counts are exchanged by a
+  // serial pass per expert (E <= 16, chunks = blockDim.x).
+  __shared__ int chunk_cnt[kMaxExperts][1024 / 64];  // per-wave counts to keep LDS small
+  const int per = (A + blockDim.x - 1) / blockDim.x;
+  const int a0 = threadIdx.x * per, a1 = min(A, a0 + per);
+  int mine[kMaxExperts];
+#pragma unroll
+  for (int e = 0; e < kMaxExperts; ++e) mine[e] = 0;
+  for (int a = a0; a < a1; ++a) {
+    const int e = topk_ids[a];
+#pragma unroll
+    for (int q = 0; q < kMaxExperts; ++q) mine[q] += (q == e) ? 1 : 0;
+  }
+  // exclusive prefix over threads for every expert: wave scan + cross-wave offsets
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  int excl[kMaxExperts];
+#pragma unroll
+  for (int e = 0; e < kMaxExperts; ++e) {
+    int incl = mine[e];
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const int o = __shfl_up(incl, off, 64);
+      if (lane >= off) incl += o;
+    }
+    excl[e] = incl - mine[e];
+    if (lane == 63) chunk_cnt[e][wid] = incl;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int e = 0; e < kMaxExperts; ++e) {
+    int before = 0;
+    for (int w = 0; w < wid && w < nw; ++w) before += chunk_cnt[e][w];
+    excl[e] += before;
+  }
+  for (int a = a0; a < a1; ++a) {
+    const int e = topk_ids[a];
+    int pos = 0;
+#pragma unroll
+    for (int q = 0; q < kMaxExperts; ++q)
+      if (q == e) pos = excl[q]++;
+    const int slot = base[e] + pos;
+    sorted_src[slot] = a / topk;
+    slot_of[a] = slot;
+  }
+}
+
+// out[t,:] = sum_k w[t,k] * Y[slot_of[t*topk+k], :]   (fp32 accumulate, bf16 store)
+__global__ void moe_combine_kernel(const bf16_t* __restrict__ Y, const int32_t* __restrict__ slot_of,
+                                   const float* __restrict__ topk_w, bf16_t* __restrict__ out, int T, int d,
+                                   int topk) {
+  const int t = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (t >= T) return;
+  for (int c = lane; c < d / 8; c += 64) {
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int k = 0; k < topk; ++k) {
+      const int slot = slot_of[static_cast<size_t>(t) * topk + k];
+      const float w = topk_w[static_cast<size_t>(t) * topk + k];
+      const bf16x8 v = *reinterpret_cast<const bf16x8*>(Y + static_cast<size_t>(slot) * d + c * 8);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[j] += w * bf16_to_f32(static_cast<bf16_t>(v[j]));
+    }
+    bf16x8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = static_cast<short>(f32_to_bf16(acc[j]));
+    *reinterpret_cast<bf16x8*>(out + static_cast<size_t>(t) * d + c * 8) = o;
+  }
+}
+
+}  // namespace
+
+LC_EXPORT int lc_moe_router(const void* x, const void* Wr, int T, int d, int E, int topk, void* topk_ids,
+                            void* topk_w, void* router_logits, hipStream_t stream) {
+  if (T <= 0) return 0;
+  if (E > kMaxExperts || topk > kMaxTopK || topk > E || d % 8) return -1;
+  moe_router_kernel<<<dim3((T + 3) / 4), dim3(256), 0, stream>>>(
+      static_cast<const bf16_t*>(x), static_cast<const bf16_t*>(Wr), T, d, E, topk,
+      static_cast<int32_t*>(topk_ids), static_cast<float*>(topk_w), static_cast<float*>(router_logits));
+  LC_RETURN_LAST_ERROR();
+}
+
+LC_EXPORT int lc_moe_permute(const void* topk_ids, int T, int topk, int E, void* offsets, void* sorted_src,
+                             void* slot_of, hipStream_t stream) {
+  if (T <= 0) return 0;
+  if (E > kMaxExperts) return -1;
+  moe_permute_kernel<<<dim3(1), dim3(1024), 0, stream>>>(static_cast<const int32_t*>(topk_ids), T * topk, topk,
+                                                         E, static_cast<int32_t*>(offsets),
+                                                         static_cast<int32_t*>(sorted_src),
+                                                         static_cast<int32_t*>(slot_of));
+  LC_RETURN_LAST_ERROR();
+}
+
+LC_EXPORT int lc_moe_combine(const void* Y, const void* slot_of, const void* topk_w, void* out, int T, int d,
+                             int topk, hipStream_t stream) {
+  if (T <= 0) return 0;
+  if (d % 8) return -1;
+  moe_combine_kernel<<<dim3((T + 3) / 4), dim3(256), 0, stream>>>(
+      static_cast<const bf16_t*>(Y), static_cast<const int32_t*>(slot_of), static_cast<const float*>(topk_w),
+      static_cast<bf16_t*>(out), T, d, topk);
+  LC_RETURN_LAST_ERROR();
+}

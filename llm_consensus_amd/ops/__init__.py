@@ -1,0 +1,375 @@
+"""Functional op layer used by the models and the engine.
+
+CUDA tensors (ROCm) go to the hand-written gfx950 kernels through ``ops.hip``; CPU
+tensors go to the PyTorch oracles in ``ops.reference`` (plumbing/tests only). There is
+no PyTorch fallback on the GPU path: if the kernel library is missing the call raises.
+"""
+from __future__ import annotations
+
+import math
+import os
+from dataclasses import dataclass
+from typing import Optional, Tuple
+
+import torch
+
+from . import reference as ref
+
+EPI_BF16, EPI_F32, EPI_SWIGLU = 0, 1, 2
+
+# M at or below which the weight-streaming kernel is used instead of the 128x128 tile kernel.
+WS_MAX_M = int(os.environ.get("LC_WS_MAX_M", "128"))
+# Target number of workgroups for the weight-streaming kernel (256 CUs on MI355X).
+WS_TARGET_BLOCKS = int(os.environ.get("LC_WS_TARGET_BLOCKS", "256"))
+
+
+def _hip():
+    from . import hip
+
+    return hip
+
+
+# ---------------------------------------------------------------------------- weights
+def pack_weight(W: torch.Tensor) -> torch.Tensor:
+    """[N, K] row-major -> MFMA-fragment order [n_pad/16, K/32, 64, 8] (see gemm.hip):
+    packed[nt, kt, lane, j] = W[nt*16 + (lane & 15), kt*32 + 8*(lane >> 4) + j]."""
+    N, K = W.shape
+    if K % 64:
+        raise ValueError(f"K={K} must be a multiple of 64")
+    n_pad = (N + 127) // 128 * 128
+    if n_pad != N:
+        W = torch.cat([W, W.new_zeros(n_pad - N, K)], 0)
+    return W.view(n_pad // 16, 16, K // 32, 4, 8).permute(0, 2, 3, 1, 4).contiguous().view(n_pad // 16, K // 32, 64, 8)
+
+
+def unpack_weight(Wp: torch.Tensor, N: int) -> torch.Tensor:
+    nt, kt = Wp.shape[0], Wp.shape[1]
+    return Wp.view(nt, kt, 4, 16, 8).permute(0, 3, 1, 2, 4).reshape(nt * 16, kt * 32)[:N].contiguous()
+
+
+def interleave_gate_up(Wg: torch.Tensor, Wu: torch.Tensor) -> torch.Tensor:
+    """Row order for the fused SwiGLU epilogue: 16-row tiles alternate gate / up."""
+    dff, K = Wg.shape
+    if dff % 16:
+        raise ValueError("d_ff must be a multiple of 16")
+    return torch.stack([Wg.view(dff // 16, 16, K), Wu.view(dff // 16, 16, K)], 1).reshape(2 * dff, K)
+
+
+@dataclass
+class LinearWeight:
+    """A linear layer's weights in device layout. ``data`` is packed on GPU and row-major
+    [N, K] on CPU. ``swiglu`` marks gate/up interleaving (output width N/2)."""
+
+    data: torch.Tensor
+    n: int
+    k: int
+    bias: Optional[torch.Tensor] = None
+    swiglu: bool = False
+
+    @property
+    def n_pad(self) -> int:
+        return (self.n + 127) // 128 * 128
+
+    @property
+    def is_packed(self) -> bool:
+        return self.data.dim() == 4
+
+    @classmethod
+    def from_dense(cls, W: torch.Tensor, bias: Optional[torch.Tensor] = None, device=None, swiglu: bool = False):
+        """W row-major [N, K] in final row order (already interleaved when swiglu)."""
+        device = torch.device(device) if device is not None else W.device
+        N, K = W.shape
+        W = W.to(device=device, dtype=torch.bfloat16)
+        b = bias.to(device=device, dtype=torch.bfloat16).contiguous() if bias is not None else None
+        data = pack_weight(W) if device.type == "cuda" else W.contiguous()
+        return cls(data, N, K, b, swiglu)
+
+    def dense(self) -> torch.Tensor:
+        return unpack_weight(self.data, self.n) if self.is_packed else self.data
+
+    def nbytes(self) -> int:
+        return self.data.numel() * self.data.element_size() + (self.bias.numel() * 2 if self.bias is not None else 0)
+
+
+def _choose_splits(n_pad: int, K: int, M: int, allow: bool) -> int:
+    if not allow:
+        return 1
+    blocks = n_pad // 128
+    kt = K // 32
+    kpi = 8 if M <= 64 else (4 if M <= 128 else 2)
+    best = 1
+    for s in (2, 3, 4, 6, 8, 12, 16):
+        if blocks * best >= WS_TARGET_BLOCKS:
+            break
+        if kt % (s * kpi) == 0 and kt // s >= 2 * kpi:
+            best = s
+    return best
+
+
+def linear(x: torch.Tensor, w: LinearWeight, out_f32: bool = False) -> torch.Tensor:
+    """y = x @ W^T (+bias). With ``w.swiglu`` returns silu(gate)*up of width N/2."""
+    M = x.shape[0]
+    out_n = w.n // 2 if w.swiglu else w.n
+    if not x.is_cuda:
+        Wd = w.dense()
+        y = ref.linear(x, Wd, w.bias, torch.float32)
+        if w.swiglu:
+            y = y.view(M, w.n // 32, 2, 16)
+            y = (torch.nn.functional.silu(y[:, :, 0]) * y[:, :, 1]).reshape(M, out_n)
+        return y if out_f32 else y.to(x.dtype)
+    h = _hip()
+    if not w.is_packed:
+        raise RuntimeError("GPU linear needs packed weights (LinearWeight.from_dense on a cuda device)")
+    x = x.contiguous()
+    epi = EPI_SWIGLU if w.swiglu else (EPI_F32 if out_f32 else EPI_BF16)
+    y = torch.empty(M, out_n, dtype=torch.float32 if (out_f32 and not w.swiglu) else torch.bfloat16, device=x.device)
+    if M == 0:
+        return y
+    if M > WS_MAX_M:
+        h.call("lc_gemm_tile", w.data.data_ptr(), x.data_ptr(), y.data_ptr(), h.ptr(w.bias), M, w.n, w.k, w.n_pad,
+               out_n, epi)
+        return y
+    splits = _choose_splits(w.n_pad, w.k, M, allow=True)
+    if splits == 1:
+        h.call("lc_wsgemm", w.data.data_ptr(), x.data_ptr(), y.data_ptr(), h.ptr(w.bias), M, w.n, w.k, w.n_pad,
+               out_n, epi, 1)
+        return y
+    part = torch.empty(splits, M, w.n, dtype=torch.float32, device=x.device)
+    h.call("lc_wsgemm", w.data.data_ptr(), x.data_ptr(), part.data_ptr(), None, M, w.n, w.k, w.n_pad, w.n, EPI_F32,
+           splits)
+    mode = 2 if w.swiglu else (1 if out_f32 else 0)
+    h.call("lc_splitk_reduce", part.data_ptr(), h.ptr(w.bias), y.data_ptr(), splits, M, w.n, out_n, mode)
+    return y
+
+
+# ---------------------------------------------------------------------------- elementwise
+def embed(ids: torch.Tensor, E: torch.Tensor) -> torch.Tensor:
+    if not ids.is_cuda:
+        return ref.embed(ids, E)
+    h = _hip()
+    T, d = ids.numel(), E.shape[1]
+    x = torch.empty(T, d, dtype=E.dtype, device=E.device)
+    h.call("lc_embed_gather", ids.data_ptr(), E.data_ptr(), x.data_ptr(), T, d, E.shape[0])
+    return x
+
+
+def rmsnorm(hstate: torch.Tensor, w: torch.Tensor, eps: float, delta: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """y = RMSNorm(hstate [+ delta]) * w. When ``delta`` is given, ``hstate`` (the residual
+    stream) is updated in place to hstate + delta first."""
+    if not hstate.is_cuda:
+        return ref.rmsnorm(hstate, w, eps, delta)
+    h = _hip()
+    T, d = hstate.shape
+    y = torch.empty_like(hstate)
+    h.call("lc_rmsnorm", hstate.data_ptr(), h.ptr(delta), w.data_ptr(), y.data_ptr(), T, d, float(eps))
+    return y
+
+
+def swiglu(gu: torch.Tensor) -> torch.Tensor:
+    if not gu.is_cuda:
+        return ref.swiglu(gu)
+    h = _hip()
+    T, two = gu.shape
+    act = torch.empty(T, two // 2, dtype=gu.dtype, device=gu.device)
+    h.call("lc_swiglu", gu.data_ptr(), act.data_ptr(), T, two // 2)
+    return act
+
+
+def add(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    if not a.is_cuda:
+        return (a.float() + b.float()).to(a.dtype)
+    h = _hip()
+    y = torch.empty_like(a)
+    h.call("lc_add", a.data_ptr(), b.data_ptr(), y.data_ptr(), a.numel())
+    return y
+
+
+def embed_pool(hidden: torch.Tensor, cu: torch.Tensor, mode: int = 0) -> torch.Tensor:
+    if not hidden.is_cuda:
+        return ref.embed_pool(hidden, cu, mode)
+    h = _hip()
+    n = cu.numel() - 1
+    out = torch.empty(n, hidden.shape[1], dtype=torch.float32, device=hidden.device)
+    h.call("lc_embed_pool", hidden.data_ptr(), cu.data_ptr(), out.data_ptr(), n, hidden.shape[1], mode)
+    return out
+
+
+# ---------------------------------------------------------------------------- rope + cache
+def rope_kv_write(qkv, positions, slot_mapping, cos_t, sin_t, k_cache, vt_cache, Hq, Hkv, Dh) -> None:
+    if not qkv.is_cuda:
+        return ref.rope_kv_write(qkv, positions, slot_mapping, cos_t, sin_t, k_cache, vt_cache, Hq, Hkv, Dh)
+    h = _hip()
+    h.call("lc_rope_kv_write", qkv.data_ptr(), positions.data_ptr(), slot_mapping.data_ptr(), cos_t.data_ptr(),
+           sin_t.data_ptr(), k_cache.data_ptr(), vt_cache.data_ptr(), qkv.shape[0], Hq, Hkv, Dh, k_cache.shape[2],
+           cos_t.shape[0])
+
+
+def copy_blocks(kv_base: torch.Tensor, src: torch.Tensor, dst: torch.Tensor, block_elems: int, n_planes: int,
+                plane_elems: int) -> None:
+    """kv_base is the flat KV pool; planes (layer x {K,V}) are plane_elems apart."""
+    if not kv_base.is_cuda:
+        flat = kv_base.view(n_planes, plane_elems // block_elems, block_elems)
+        flat[:, dst.long()] = flat[:, src.long()]
+        return
+    h = _hip()
+    es = kv_base.element_size()
+    h.call("lc_copy_blocks", kv_base.data_ptr(), src.data_ptr(), dst.data_ptr(), src.numel(), block_elems * es,
+           plane_elems * es, n_planes)
+
+
+# ---------------------------------------------------------------------------- attention
+def attn_prefill(qkv, k_cache, vt_cache, block_tables, cu_q, ctx_lens, max_q_len, Hq, Hkv, Dh, scale,
+                 window: int = 0) -> torch.Tensor:
+    """qkv [T, (Hq+2Hkv)*Dh] after rope_kv_write; returns [T, Hq*Dh]."""
+    T = qkv.shape[0]
+    if not qkv.is_cuda:
+        return ref.attn_prefill(qkv[:, : Hq * Dh], k_cache, vt_cache, block_tables, cu_q, ctx_lens, Hq, Hkv, Dh,
+                                scale, window)
+    h = _hip()
+    out = torch.empty(T, Hq * Dh, dtype=qkv.dtype, device=qkv.device)
+    h.call("lc_attn_prefill", qkv.data_ptr(), qkv.stride(0), k_cache.data_ptr(), vt_cache.data_ptr(),
+           block_tables.data_ptr(), block_tables.shape[1], cu_q.data_ptr(), ctx_lens.data_ptr(), out.data_ptr(),
+           ctx_lens.numel(), int(max_q_len), Hq, Hkv, Dh, k_cache.shape[2], float(scale), int(window))
+    return out
+
+
+def choose_kv_splits(B: int, Hkv: int, max_ctx: int) -> int:
+    """Enough waves to occupy the chip (256 CUs x several waves) without slicing below 128 keys."""
+    waves = max(1, B * Hkv)
+    want = max(1, 2048 // waves)
+    cap = max(1, max_ctx // 128)
+    return int(max(1, min(want, cap, 16)))
+
+
+def attn_decode(qkv, k_cache, vt_cache, block_tables, ctx_lens, Hq, Hkv, Dh, scale, window: int = 0,
+                nsplit: int = 1, groups: Optional[Tuple[torch.Tensor, torch.Tensor, torch.Tensor]] = None,
+                kv_begin: Optional[torch.Tensor] = None, max_group_rows: int = 0,
+                prefix_splits: int = 1) -> torch.Tensor:
+    """One query token per row of qkv [B, (Hq+2Hkv)*Dh]. ``groups`` = (first, count,
+    shared_blocks) int32 device tensors enables the shared-prefix pass: rows of a group
+    attend to their common leading blocks in one MFMA pass and ``kv_begin`` [B] tells the
+    per-row pass where each row's private suffix starts."""
+    B = qkv.shape[0]
+    if not qkv.is_cuda:
+        return ref.attn_decode(qkv[:, : Hq * Dh], k_cache, vt_cache, block_tables, ctx_lens, Hq, Hkv, Dh, scale,
+                               window)
+    h = _hip()
+    out = torch.empty(B, Hq * Dh, dtype=qkv.dtype, device=qkv.device)
+    use_prefix = groups is not None and max_group_rows > 1
+    if nsplit == 1 and not use_prefix:
+        h.call("lc_attn_decode", qkv.data_ptr(), qkv.stride(0), k_cache.data_ptr(), vt_cache.data_ptr(),
+               block_tables.data_ptr(), block_tables.shape[1], ctx_lens.data_ptr(), None, out.data_ptr(), None, None,
+               1, 1, B, Hq, Hkv, Dh, k_cache.shape[2], float(scale), int(window))
+        return out
+    np_total = nsplit + (prefix_splits if use_prefix else 0)
+    part_o = torch.empty(B, Hq, np_total, Dh, dtype=torch.float32, device=qkv.device)
+    part_lse = torch.empty(B, Hq, np_total, dtype=torch.float32, device=qkv.device)
+    if use_prefix:
+        h.call("lc_fill_f32", part_lse.data_ptr(), -1.0e30, part_lse.numel())
+    h.call("lc_attn_decode", qkv.data_ptr(), qkv.stride(0), k_cache.data_ptr(), vt_cache.data_ptr(),
+           block_tables.data_ptr(), block_tables.shape[1], ctx_lens.data_ptr(),
+           kv_begin.data_ptr() if (use_prefix and kv_begin is not None) else None, out.data_ptr(), part_o.data_ptr(),
+           part_lse.data_ptr(), np_total, nsplit, B, Hq, Hkv, Dh, k_cache.shape[2], float(scale), int(window))
+    if use_prefix:
+        gf, gc, gs = groups
+        h.call("lc_attn_prefix", qkv.data_ptr(), qkv.stride(0), k_cache.data_ptr(), vt_cache.data_ptr(),
+               block_tables.data_ptr(), block_tables.shape[1], gf.data_ptr(), gc.data_ptr(), gs.data_ptr(),
+               gf.numel(), int(max_group_rows), int(prefix_splits), part_o.data_ptr(), part_lse.data_ptr(), np_total,
+               nsplit, Hq, Hkv, Dh, k_cache.shape[2], float(scale))
+    h.call("lc_attn_merge", part_o.data_ptr(), part_lse.data_ptr(), out.data_ptr(), np_total, B * Hq, Dh)
+    return out
+
+
+# ---------------------------------------------------------------------------- sampling
+def sample(logits, temperature, top_p, top_k, seeds, steps, row_index=None):
+    """logits fp32 [*, V]; per-row params are device tensors (float32/float32/int32/int64/int32).
+    Returns (tokens int32 [R], logprobs float32 [R])."""
+    if not logits.is_cuda:
+        return ref.sample(logits, temperature, top_p, top_k, seeds, steps, row_index)
+    h = _hip()
+    R = temperature.numel()
+    tok = torch.empty(R, dtype=torch.int32, device=logits.device)
+    lp = torch.empty(R, dtype=torch.float32, device=logits.device)
+    h.call("lc_sample", logits.data_ptr(), logits.shape[1], logits.stride(0), h.ptr(row_index),
+           temperature.data_ptr(), h.ptr(top_p), h.ptr(top_k), seeds.data_ptr(), h.ptr(steps), tok.data_ptr(),
+           lp.data_ptr(), R)
+    return tok, lp
+
+
+def logprob_gather(logits, ids, row_index=None) -> torch.Tensor:
+    """log_softmax(logits[row])[ids]. ids int32 [C] (shared) or [R, C]."""
+    if not logits.is_cuda:
+        return ref.logprob_gather(logits, ids, row_index)
+    h = _hip()
+    R = row_index.numel() if row_index is not None else logits.shape[0]
+    C = ids.shape[-1]
+    out = torch.empty(R, C, dtype=torch.float32, device=logits.device)
+    h.call("lc_logprob_gather", logits.data_ptr(), logits.shape[1], logits.stride(0), h.ptr(row_index),
+           ids.data_ptr(), C if ids.dim() == 2 else 0, C, out.data_ptr(), R)
+    return out
+
+
+# ---------------------------------------------------------------------------- MoE
+@dataclass
+class ExpertWeights:
+    """Stacked per-expert weights. GPU: packed [E, n_pad/16, K/32, 64, 8]; CPU: [E, N, K]."""
+
+    data: torch.Tensor
+    n: int
+    k: int
+    swiglu: bool = False
+
+    @property
+    def n_pad(self) -> int:
+        return (self.n + 127) // 128 * 128
+
+    @classmethod
+    def from_dense(cls, W: torch.Tensor, device=None, swiglu: bool = False):
+        device = torch.device(device) if device is not None else W.device
+        E, N, K = W.shape
+        W = W.to(device=device, dtype=torch.bfloat16)
+        data = torch.stack([pack_weight(W[e]) for e in range(E)]) if device.type == "cuda" else W.contiguous()
+        return cls(data, N, K, swiglu)
+
+    def nbytes(self) -> int:
+        return self.data.numel() * self.data.element_size()
+
+
+def moe_ffn(x: torch.Tensor, Wr: torch.Tensor, w_gate_up: ExpertWeights, w_down: ExpertWeights, topk: int):
+    """Mixtral block-sparse FFN: route, run the selected experts' SwiGLU MLP, combine."""
+    T, d = x.shape
+    E = Wr.shape[0]
+    if not x.is_cuda:
+        ids, wts, _ = ref.moe_router(x, Wr, topk)
+        out = torch.zeros(T, d, dtype=torch.float32)
+        for e in range(E):
+            tok, slot = torch.nonzero(ids == e, as_tuple=True)
+            if tok.numel() == 0:
+                continue
+            xe = x[tok]
+            gu = ref.linear(xe, w_gate_up.data[e], None, torch.float32)
+            gu = gu.view(-1, w_gate_up.n // 32, 2, 16)
+            act = (torch.nn.functional.silu(gu[:, :, 0]) * gu[:, :, 1]).reshape(tok.numel(), -1).to(x.dtype)
+            ye = ref.linear(act, w_down.data[e], None, x.dtype).float()
+            out.index_add_(0, tok, ye * wts[tok, slot][:, None])
+        return out.to(x.dtype)
+    h = _hip()
+    dev = x.device
+    ids = torch.empty(T, topk, dtype=torch.int32, device=dev)
+    wts = torch.empty(T, topk, dtype=torch.float32, device=dev)
+    h.call("lc_moe_router", x.data_ptr(), Wr.data_ptr(), T, d, E, topk, ids.data_ptr(), wts.data_ptr(), None)
+    offsets = torch.empty(E + 1, dtype=torch.int32, device=dev)
+    sorted_src = torch.empty(T * topk, dtype=torch.int32, device=dev)
+    slot_of = torch.empty(T * topk, dtype=torch.int32, device=dev)
+    h.call("lc_moe_permute", ids.data_ptr(), T, topk, E, offsets.data_ptr(), sorted_src.data_ptr(), slot_of.data_ptr())
+    dff = w_gate_up.n // 2
+    act = torch.empty(T * topk, dff, dtype=x.dtype, device=dev)
+    h.call("lc_gemm_grouped", w_gate_up.data.data_ptr(), w_gate_up.data[0].numel(), x.data_ptr(),
+           sorted_src.data_ptr(), offsets.data_ptr(), E, act.data_ptr(), T * topk, w_gate_up.n, w_gate_up.k,
+           w_gate_up.n_pad, dff, EPI_SWIGLU)
+    y = torch.empty(T * topk, d, dtype=x.dtype, device=dev)
+    h.call("lc_gemm_grouped", w_down.data.data_ptr(), w_down.data[0].numel(), act.data_ptr(), None,
+           offsets.data_ptr(), E, y.data_ptr(), T * topk, w_down.n, w_down.k, w_down.n_pad, d, EPI_BF16)
+    out = torch.empty(T, d, dtype=x.dtype, device=dev)
+    h.call("lc_moe_combine", y.data_ptr(), slot_of.data_ptr(), wts.data_ptr(), out.data_ptr(), T, d, topk)
+    return out

@@ -1,0 +1,79 @@
+"""ctypes bindings of the gfx950 kernel library (csrc/kernels/*.hip).
+
+Every launcher takes raw device pointers plus the current HIP stream, so launches are
+captured by ``torch.cuda.graph`` (hipGraph) like any other work on the stream. Nothing
+here falls back to PyTorch: a missing library or a non-zero launcher status raises.
+"""
+from __future__ import annotations
+
+import ctypes
+from ctypes import c_float, c_int, c_longlong, c_void_p
+from typing import Optional
+
+import torch
+
+from .._native import kernels
+
+_P, _I, _F, _L = c_void_p, c_int, c_float, c_longlong
+
+_SIGNATURES = {
+    "lc_embed_gather": [_P, _P, _P, _I, _I, _I, _P],
+    "lc_rmsnorm": [_P, _P, _P, _P, _I, _I, _F, _P],
+    "lc_swiglu": [_P, _P, _I, _I, _P],
+    "lc_add": [_P, _P, _P, _L, _P],
+    "lc_copy_blocks": [_P, _P, _P, _I, _L, _L, _I, _P],
+    "lc_embed_pool": [_P, _P, _P, _I, _I, _I, _P],
+    "lc_gemm_tile": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
+    "lc_wsgemm": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
+    "lc_splitk_reduce": [_P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "lc_gemm_grouped": [_P, _L, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _P],
+    "lc_rope_kv_write": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
+    "lc_attn_prefill": [_P, _I, _P, _P, _P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _F, _I, _P],
+    "lc_attn_decode": [_P, _I, _P, _P, _P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _F, _I, _P],
+    "lc_attn_prefix": [_P, _I, _P, _P, _P, _I, _P, _P, _P, _I, _I, _I, _P, _P, _I, _I, _I, _I, _I, _I, _F, _P],
+    "lc_attn_merge": [_P, _P, _P, _I, _I, _I, _P],
+    "lc_fill_f32": [_P, _F, _L, _P],
+    "lc_sample": [_P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P],
+    "lc_logprob_gather": [_P, _I, _I, _P, _P, _I, _I, _P, _I, _P],
+    "lc_majority_vote": [_P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P],
+    "lc_cosine_medoid": [_P, _I, _I, _I, _L, _P, _P, _P, _P],
+    "lc_judge_reduce": [_P, _I, _I, _I, _P, _P, _P, _P],
+    "lc_moe_router": [_P, _P, _I, _I, _I, _I, _P, _P, _P, _P],
+    "lc_moe_permute": [_P, _I, _I, _I, _P, _P, _P, _P],
+    "lc_moe_combine": [_P, _P, _P, _P, _I, _I, _I, _P],
+}
+
+_lib = None
+
+
+class KernelLaunchError(RuntimeError):
+    pass
+
+
+def lib() -> ctypes.CDLL:
+    global _lib
+    if _lib is None:
+        l = kernels()
+        for name, argtypes in _SIGNATURES.items():
+            fn = getattr(l, name)
+            fn.argtypes = argtypes
+            fn.restype = c_int
+        _lib = l
+    return _lib
+
+
+def ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    if t is None:
+        return None
+    return t.data_ptr()
+
+
+def stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def call(name: str, *args) -> None:
+    rc = getattr(lib(), name)(*args, stream())
+    if rc != 0:
+        what = "invalid arguments for this kernel" if rc < 0 else f"HIP error {rc}"
+        raise KernelLaunchError(f"{name} failed: {what}")

@@ -1,0 +1,378 @@
+"""Numerics of every HIP kernel against the plain-PyTorch fp32 oracles (ops/reference.py).
+Runs only on a real MI355X (``-m gpu``)."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from llm_consensus_amd import ops
+from llm_consensus_amd.ops import reference as ref
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def bf(x):
+    return x.to(torch.bfloat16)
+
+
+def rand(*shape, scale=1.0, seed=0):
+    g = torch.Generator().manual_seed(seed + sum(shape))
+    return (torch.randn(*shape, generator=g) * scale)
+
+
+def rel_err(a, b):
+    a, b = a.float().cpu(), b.float().cpu()
+    return float((a - b).norm() / (b.norm() + 1e-12))
+
+
+# ------------------------------------------------------------------ packing (CPU-safe but kept with its users)
+def test_pack_roundtrip():
+    W = bf(rand(200, 128))
+    Wp = ops.pack_weight(W)
+    assert Wp.shape == (16, 4, 64, 8)
+    assert torch.equal(ops.unpack_weight(Wp, 200), W)
+    # the documented lane map
+    nt, kt, lane, j = 3, 2, 37, 5
+    assert Wp[nt, kt, lane, j] == W[nt * 16 + (lane & 15), kt * 32 + 8 * (lane >> 4) + j]
+
+
+# ------------------------------------------------------------------ GEMM
+@pytest.mark.parametrize("M,N,K", [(512, 256, 256), (300, 1152, 896), (1000, 384, 4096), (129, 128, 64)])
+@pytest.mark.parametrize("bias", [False, True])
+def test_gemm_tile(M, N, K, bias):
+    # asymmetric operands: row/col index baked into the values catches transposed tiles
+    X = bf(rand(M, K, scale=0.5) + torch.arange(M)[:, None] * 1e-3)
+    W = bf(rand(N, K, scale=0.5, seed=1) + torch.arange(N)[:, None] * 1e-3)
+    b = bf(rand(N, seed=2)) if bias else None
+    lw = ops.LinearWeight.from_dense(W, b, DEV)
+    ops.WS_MAX_M = 0
+    try:
+        y = ops.linear(X.to(DEV), lw)
+        y32 = ops.linear(X.to(DEV), lw, out_f32=True)
+    finally:
+        ops.WS_MAX_M = 128
+    want = ref.linear(X, W, b, torch.float32)
+    assert rel_err(y, want) < 6e-3
+    assert rel_err(y32, want) < 1e-4
+
+
+@pytest.mark.parametrize("M", [1, 7, 16, 33, 64, 100, 128, 200, 256])
+@pytest.mark.parametrize("N,K", [(256, 1024), (1152, 896), (128, 4096)])
+def test_wsgemm_with_and_without_splitk(M, N, K):
+    X = bf(rand(M, K, scale=0.5) + torch.arange(M)[:, None] * 1e-3)
+    W = bf(rand(N, K, scale=0.5, seed=1) + torch.arange(N)[:, None] * 1e-3)
+    b = bf(rand(N, seed=2))
+    lw = ops.LinearWeight.from_dense(W, b, DEV)
+    want = ref.linear(X, W, b, torch.float32)
+    old = ops.WS_MAX_M, ops.WS_TARGET_BLOCKS
+    try:
+        ops.WS_MAX_M = 256
+        for target in (1, 4096):      # 1 => no split-K, 4096 => as many splits as allowed
+            ops.WS_TARGET_BLOCKS = target
+            assert rel_err(ops.linear(X.to(DEV), lw), want) < 6e-3
+            assert rel_err(ops.linear(X.to(DEV), lw, out_f32=True), want) < 1e-4
+    finally:
+        ops.WS_MAX_M, ops.WS_TARGET_BLOCKS = old
+
+
+@pytest.mark.parametrize("M", [5, 64, 128, 400])
+def test_fused_swiglu_epilogue(M):
+    K, dff = 256, 384
+    X = bf(rand(M, K, scale=0.5))
+    Wg, Wu = bf(rand(dff, K, scale=0.3, seed=3)), bf(rand(dff, K, scale=0.3, seed=4))
+    lw = ops.LinearWeight.from_dense(ops.interleave_gate_up(Wg, Wu), None, DEV, swiglu=True)
+    want = (torch.nn.functional.silu(X.float() @ Wg.float().t()) * (X.float() @ Wu.float().t()))
+    old = ops.WS_TARGET_BLOCKS
+    try:
+        for target in (1, 4096):
+            ops.WS_TARGET_BLOCKS = target
+            got = ops.linear(X.to(DEV), lw)
+            assert got.shape == (M, dff) and rel_err(got, want) < 8e-3
+    finally:
+        ops.WS_TARGET_BLOCKS = old
+    # CPU path uses the same interleaved layout
+    lw_cpu = ops.LinearWeight.from_dense(ops.interleave_gate_up(Wg, Wu), None, "cpu", swiglu=True)
+    assert rel_err(ops.linear(X, lw_cpu), want) < 8e-3
+
+
+# ------------------------------------------------------------------ row kernels
+@pytest.mark.parametrize("d", [896, 4096, 8192])
+def test_rmsnorm_and_residual(d):
+    T = 37
+    h, delta, w = bf(rand(T, d)), bf(rand(T, d, seed=5)), bf(rand(d, seed=6) * 0.1 + 1)
+    hg = h.to(DEV).clone()
+    y = ops.rmsnorm(hg, w.to(DEV), 1e-5)
+    assert rel_err(y, ref.rmsnorm(h.clone(), w, 1e-5)) < 4e-3
+    hg = h.to(DEV).clone()
+    y = ops.rmsnorm(hg, w.to(DEV), 1e-6, delta.to(DEV))
+    hc = h.clone()
+    want = ref.rmsnorm(hc, w, 1e-6, delta)
+    assert torch.equal(hg.cpu(), hc)          # residual stream updated identically
+    assert rel_err(y, want) < 4e-3
+
+
+def test_embed_swiglu_add_pool():
+    E = bf(rand(1000, 896))
+    ids = torch.randint(0, 1000, (77,), dtype=torch.int32)
+    assert torch.equal(ops.embed(ids.to(DEV), E.to(DEV)).cpu(), E[ids.long()])
+    gu = bf(rand(33, 2 * 4864))
+    assert rel_err(ops.swiglu(gu.to(DEV)), ref.swiglu(gu)) < 4e-3
+    a, b = bf(rand(9, 1024)), bf(rand(9, 1024, seed=1))
+    assert rel_err(ops.add(a.to(DEV), b.to(DEV)), a.float() + b.float()) < 4e-3
+    hid = bf(rand(20, 256))
+    cu = torch.tensor([0, 5, 5, 20], dtype=torch.int32)
+    for mode in (0, 1):
+        assert rel_err(ops.embed_pool(hid.to(DEV), cu.to(DEV), mode), ref.embed_pool(hid, cu, mode)) < 1e-5
+
+
+# ------------------------------------------------------------------ rope + cache + attention
+def make_cache(nblocks, Hkv, BS, Dh, device):
+    k = torch.zeros(nblocks, Hkv, BS, Dh, dtype=torch.bfloat16, device=device)
+    v = torch.zeros(nblocks, Hkv, Dh, BS, dtype=torch.bfloat16, device=device)
+    return k, v
+
+
+def build_paged_context(lens, Hq, Hkv, Dh, BS, seed=0, device="cpu"):
+    """Random sequences written token by token through rope_kv_write (reference impl) into a
+    shuffled block pool. Returns caches, block tables and the per-token qkv rows."""
+    g = torch.Generator().manual_seed(seed)
+    nb = [math.ceil(n / BS) for n in lens]
+    total = sum(nb) + 3
+    perm = torch.randperm(total, generator=g).tolist()
+    tables = torch.full((len(lens), max(nb)), -1, dtype=torch.int32)
+    it = iter(perm)
+    for s, n in enumerate(nb):
+        for j in range(n):
+            tables[s, j] = next(it)
+    kc, vc = make_cache(total, Hkv, BS, Dh, "cpu")
+    cos_t, sin_t = ref.rope_tables(Dh, max(lens) + 8, 10000.0)
+    qkvs = []
+    for s, n in enumerate(lens):
+        qkv = bf(torch.randn(n, (Hq + 2 * Hkv) * Dh, generator=g))
+        pos = torch.arange(n, dtype=torch.int32)
+        slots = torch.tensor([int(tables[s, p // BS]) * BS + p % BS for p in range(n)], dtype=torch.int32)
+        ref.rope_kv_write(qkv, pos, slots, cos_t, sin_t, kc, vc, Hq, Hkv, Dh)
+        qkvs.append(qkv)
+    return kc.to(device), vc.to(device), tables.to(device), qkvs, (cos_t, sin_t)
+
+
+@pytest.mark.parametrize("Hq,Hkv,Dh,BS", [(8, 2, 128, 64), (14, 2, 64, 16), (8, 1, 128, 32)])
+def test_rope_kv_write_matches_reference(Hq, Hkv, Dh, BS):
+    T, nblocks = 50, 8
+    qkv = bf(rand(T, (Hq + 2 * Hkv) * Dh))
+    pos = torch.randint(0, 300, (T,), dtype=torch.int32)
+    slots = torch.randperm(nblocks * BS)[:T].to(torch.int32)
+    slots[7] = -1
+    cos_t, sin_t = ref.rope_tables(Dh, 512, 1e6)
+    kc, vc = make_cache(nblocks, Hkv, BS, Dh, "cpu")
+    q_ref = qkv.clone()
+    ref.rope_kv_write(q_ref, pos, slots, cos_t, sin_t, kc, vc, Hq, Hkv, Dh)
+    kg, vg = make_cache(nblocks, Hkv, BS, Dh, DEV)
+    q_gpu = qkv.to(DEV)
+    ops.rope_kv_write(q_gpu, pos.to(DEV), slots.to(DEV), cos_t.to(DEV), sin_t.to(DEV), kg, vg, Hq, Hkv, Dh)
+    assert rel_err(q_gpu[:, : Hq * Dh], q_ref[:, : Hq * Dh]) < 4e-3
+    assert rel_err(kg, kc) < 4e-3 and torch.equal(vg.cpu(), vc)
+
+
+@pytest.mark.parametrize("Hq,Hkv,Dh,BS,window", [(8, 2, 128, 64, 0), (14, 2, 64, 16, 0), (8, 1, 128, 32, 0),
+                                                  (4, 4, 128, 64, 0), (8, 2, 128, 64, 40)])
+def test_attn_prefill_chunked_matches_reference(Hq, Hkv, Dh, BS, window):
+    lens = [1, 31, 32, 33, 200, 77]
+    kc, vc, tables, qkvs, _ = build_paged_context(lens, Hq, Hkv, Dh, BS, seed=1, device=DEV)
+    # second half of every sequence is the "new chunk": queries see the whole earlier context
+    q_lens = [max(1, n // 2) for n in lens]
+    rows = torch.cat([qkvs[s][lens[s] - q_lens[s]:] for s in range(len(lens))])
+    cu = torch.tensor([0] + list(np.cumsum(q_lens)), dtype=torch.int32)
+    ctx = torch.tensor(lens, dtype=torch.int32)
+    scale = Dh ** -0.5
+    got = ops.attn_prefill(rows.to(DEV), kc, vc, tables, cu.to(DEV), ctx.to(DEV), max(q_lens), Hq, Hkv, Dh, scale,
+                           window)
+    want = ref.attn_prefill(rows[:, : Hq * Dh], kc.cpu(), vc.cpu(), tables.cpu(), cu, ctx, Hq, Hkv, Dh, scale, window)
+    assert rel_err(got, want) < 1e-2
+    assert float((got.float().cpu() - want.float()).abs().max()) < 0.06
+
+
+def test_attn_online_softmax_rescale_branch():
+    """A key far above the rest late in the context forces the running max to jump after
+    many tiles have been accumulated (the branch bounded random data never exercises)."""
+    Hq, Hkv, Dh, BS = 4, 1, 128, 64
+    lens = [300]
+    kc, vc, tables, qkvs, _ = build_paged_context(lens, Hq, Hkv, Dh, BS, seed=3, device="cpu")
+    q = qkvs[0][-1:].clone()
+    # plant a key aligned with head 0's query at position 257 (9th tile)
+    blk, off = int(tables[0, 257 // BS]), 257 % BS
+    kc[blk, 0, off, :] = (q[0, :Dh].float() * 3).to(torch.bfloat16)
+    ctx = torch.tensor(lens, dtype=torch.int32)
+    scale = Dh ** -0.5
+    want = ref.attn_decode(q[:, : Hq * Dh], kc, vc, tables, ctx, Hq, Hkv, Dh, scale)
+    for nsplit in (1, 3):
+        got = ops.attn_decode(q.to(DEV), kc.to(DEV), vc.to(DEV), tables.to(DEV), ctx.to(DEV), Hq, Hkv, Dh, scale,
+                              nsplit=nsplit)
+        assert rel_err(got, want) < 1e-2
+
+
+@pytest.mark.parametrize("Hq,Hkv,Dh,BS", [(8, 2, 128, 64), (14, 2, 64, 16), (16, 2, 128, 32), (28, 4, 128, 64)])
+@pytest.mark.parametrize("nsplit", [1, 4])
+def test_attn_decode_matches_reference(Hq, Hkv, Dh, BS, nsplit):
+    lens = [1, 17, 64, 65, 500, 129]
+    kc, vc, tables, qkvs, _ = build_paged_context(lens, Hq, Hkv, Dh, BS, seed=2, device=DEV)
+    rows = torch.stack([qkvs[s][-1] for s in range(len(lens))])
+    ctx = torch.tensor(lens, dtype=torch.int32)
+    scale = Dh ** -0.5
+    got = ops.attn_decode(rows.to(DEV), kc, vc, tables, ctx.to(DEV), Hq, Hkv, Dh, scale, nsplit=nsplit)
+    want = ref.attn_decode(rows[:, : Hq * Dh], kc.cpu(), vc.cpu(), tables.cpu(), ctx, Hq, Hkv, Dh, scale)
+    assert rel_err(got, want) < 1e-2
+
+
+@pytest.mark.parametrize("Hq,Hkv,Dh,BS,K", [(8, 2, 128, 64, 16), (14, 2, 64, 16, 5), (8, 1, 128, 32, 3)])
+def test_shared_prefix_decode_equals_unshared(Hq, Hkv, Dh, BS, K):
+    """K chains forked from one prompt: prefix pass + per-chain suffix pass + merge must
+    equal plain per-chain decode over the full context."""
+    g = torch.Generator().manual_seed(11)
+    P = 3 * BS + 5                      # prompt: 3 full shared blocks + a partial one
+    extra = [1 + (c * 7) % 40 for c in range(K)]   # tokens each chain generated so far
+    lens = [P + e for e in extra]
+    # build chain 0 normally, then make the other chains share its first 3 blocks
+    kc, vc, tables, qkvs, _ = build_paged_context(lens, Hq, Hkv, Dh, BS, seed=4, device="cpu")
+    for c in range(1, K):
+        tables[c, :3] = tables[0, :3]
+    # a lone sequence in the same batch (no group) plus a 2-chain group
+    rows = torch.stack([qkvs[c][-1] for c in range(K)])
+    ctx = torch.tensor(lens, dtype=torch.int32)
+    scale = Dh ** -0.5
+    want = ref.attn_decode(rows[:, : Hq * Dh], kc, vc, tables, ctx, Hq, Hkv, Dh, scale)
+    groups = (torch.tensor([0], dtype=torch.int32, device=DEV), torch.tensor([K], dtype=torch.int32, device=DEV),
+              torch.tensor([3], dtype=torch.int32, device=DEV))
+    kv_begin = torch.full((K,), 3 * BS, dtype=torch.int32, device=DEV)
+    for nsplit, psplit in ((1, 1), (2, 3)):
+        got = ops.attn_decode(rows.to(DEV), kc.to(DEV), vc.to(DEV), tables.to(DEV), ctx.to(DEV), Hq, Hkv, Dh, scale,
+                              nsplit=nsplit, groups=groups, kv_begin=kv_begin, max_group_rows=K, prefix_splits=psplit)
+        assert rel_err(got, want) < 1e-2
+
+
+def test_copy_blocks():
+    L, nb, be = 3, 10, 64 * 8
+    pool = bf(rand(L * 2, nb, be)).to(DEV)
+    want = pool.clone()
+    src = torch.tensor([1, 4], dtype=torch.int32, device=DEV)
+    dst = torch.tensor([7, 2], dtype=torch.int32, device=DEV)
+    want[:, 7], want[:, 2] = want[:, 1].clone(), want[:, 4].clone()
+    ops.copy_blocks(pool, src, dst, be, L * 2, nb * be)
+    assert torch.equal(pool, want)
+
+
+# ------------------------------------------------------------------ sampling
+def test_greedy_and_logprob_gather():
+    V, R = 151936, 5
+    logits = rand(R + 2, V, scale=3.0)
+    idx = torch.tensor([6, 0, 3, 3, 1], dtype=torch.int32)
+    z = torch.zeros(R)
+    tok, lp = ops.sample(logits.to(DEV), z.to(DEV), None, None, torch.zeros(R, dtype=torch.int64, device=DEV), None,
+                         idx.to(DEV))
+    rows = logits[idx.long()]
+    assert torch.equal(tok.cpu().long(), rows.argmax(-1))
+    assert torch.allclose(lp.cpu(), torch.log_softmax(rows, -1).max(-1).values, atol=1e-4)
+    ids = torch.tensor([[5, 77, 151935], [0, 1, 2], [9, 9, 9], [100, 200, 300], [4, 3, 2]], dtype=torch.int32)
+    got = ops.logprob_gather(logits.to(DEV), ids.to(DEV), idx.to(DEV))
+    assert torch.allclose(got.cpu(), ref.logprob_gather(logits, ids, idx), atol=1e-4)
+    shared = torch.tensor([11, 22], dtype=torch.int32)
+    got = ops.logprob_gather(logits.to(DEV), shared.to(DEV))
+    assert torch.allclose(got.cpu(), ref.logprob_gather(logits, shared), atol=1e-4)
+
+
+@pytest.mark.parametrize("V", [1000, 32000, 128256])
+def test_sampler_matches_reference_definition(V):
+    R = 24
+    logits = rand(R, V, scale=2.5, seed=V)
+    temp = torch.tensor([0.7, 1.0, 1.3] * 8)
+    top_p = torch.tensor([1.0, 0.9, 0.5, 0.95] * 6)
+    top_k = torch.tensor([0, 50, 0, 5, 0, 1] * 4, dtype=torch.int32)
+    seeds = torch.arange(R, dtype=torch.int64) * 7919 + 3
+    steps = torch.arange(R, dtype=torch.int32) % 5
+    tok, lp = ops.sample(logits.to(DEV), temp.to(DEV), top_p.to(DEV), top_k.to(DEV), seeds.to(DEV), steps.to(DEV))
+    wt, wl = ref.sample(logits, temp, top_p, top_k, seeds, steps)
+    same = (tok.cpu() == wt).float().mean()
+    assert same >= 0.9, (tok.cpu(), wt)            # identical u; only fp rounding at a CDF boundary may differ
+    m = tok.cpu() == wt
+    assert torch.allclose(lp.cpu()[m], wl[m], atol=2e-3)
+
+
+def test_sampler_statistics_and_reproducibility():
+    V, R = 64, 4096
+    base = torch.tensor([2.0, 1.0, 0.5, 0.0] + [-4.0] * (V - 4))
+    logits = base[None].repeat(R, 1)
+    temp = torch.ones(R)
+    seeds = torch.arange(R, dtype=torch.int64) + 100
+    args = (logits.to(DEV), temp.to(DEV), None, None, seeds.to(DEV), None)
+    tok, _ = ops.sample(*args)
+    tok2, _ = ops.sample(*args)
+    assert torch.equal(tok, tok2)
+    freq = torch.bincount(tok.cpu().long(), minlength=V).float() / R
+    p = torch.softmax(base, -1)
+    assert float((freq[:4] - p[:4]).abs().max()) < 0.03
+    # top-k=2 confines samples to the two best tokens, renormalised
+    tk = torch.full((R,), 2, dtype=torch.int32)
+    tok, _ = ops.sample(logits.to(DEV), temp.to(DEV), None, tk.to(DEV), seeds.to(DEV), None)
+    assert set(tok.cpu().tolist()) <= {0, 1}
+    assert abs(float((tok == 0).float().mean()) - float(p[0] / (p[0] + p[1]))) < 0.03
+
+
+# ------------------------------------------------------------------ consensus reducers
+def test_majority_vote_kernel_matches_host():
+    from llm_consensus_amd._native import core
+    from llm_consensus_amd.consensus import reducers
+
+    rng = np.random.default_rng(0)
+    for N, C in ((3, 4), (16, 4), (100, 7), (64, 64)):
+        votes = rng.integers(-1, C, size=(257, N)).astype(np.int32)
+        for tie in (core.TieBreak.LowestClass, core.TieBreak.FirstVoter):
+            host = reducers.majority_vote_batch(votes, C, tie)
+            dev = reducers.majority_vote_batch(votes, C, tie, device=DEV)
+            for f in ("winner", "count", "valid", "unanimous"):
+                assert np.array_equal(getattr(host, f), getattr(dev, f)), (N, C, f)
+            assert np.allclose(host.agreement, dev.agreement)
+
+
+def test_cosine_medoid_and_judge_kernels_match_host():
+    from llm_consensus_amd.consensus import reducers
+
+    rng = np.random.default_rng(1)
+    for n, d in ((2, 8), (5, 896), (16, 4096), (33, 384), (64, 128)):
+        E = rng.normal(size=(n, d)).astype(np.float32)
+        E[0] = E[1] * 0.5 + 0.1 * E[0]
+        h, g = reducers.cosine_medoid(E), reducers.cosine_medoid(E, device=DEV)
+        assert h.index == g.index and abs(h.score - g.score) < 1e-4 and abs(h.mean_pairwise - g.mean_pairwise) < 1e-4
+    s = rng.normal(size=(50, 4, 3)).astype(np.float32)
+    s[0, 2] = 10
+    h, g = reducers.judge_reduce_batch(s), reducers.judge_reduce_batch(s, device=DEV)
+    assert np.array_equal(h.winner, g.winner) and np.array_equal(h.unanimous, g.unanimous)
+    assert np.allclose(h.score, g.score, atol=1e-5)
+
+
+# ------------------------------------------------------------------ MoE
+@pytest.mark.parametrize("T", [1, 9, 64, 300])
+def test_moe_ffn_matches_reference(T):
+    d, dff, E, topk = 256, 384, 8, 2
+    x = bf(rand(T, d, scale=0.7))
+    Wr = bf(rand(E, d, scale=0.2, seed=1))
+    Wg, Wu = bf(rand(E, dff, d, scale=0.1, seed=2)), bf(rand(E, dff, d, scale=0.1, seed=3))
+    Wd = bf(rand(E, d, dff, scale=0.1, seed=4))
+    Wgu = torch.stack([ops.interleave_gate_up(Wg[e], Wu[e]) for e in range(E)])
+    cpu = ops.moe_ffn(x, Wr, ops.ExpertWeights.from_dense(Wgu, "cpu", True), ops.ExpertWeights.from_dense(Wd, "cpu"),
+                      topk)
+    gpu = ops.moe_ffn(x.to(DEV), Wr.to(DEV), ops.ExpertWeights.from_dense(Wgu, DEV, True),
+                      ops.ExpertWeights.from_dense(Wd, DEV), topk)
+    # independent dense oracle
+    p = torch.softmax((x.float() @ Wr.float().t()).to(torch.bfloat16).float(), -1)
+    w, ids = torch.topk(p, topk, -1)
+    w = w / w.sum(-1, keepdim=True)
+    want = torch.zeros(T, d)
+    for t in range(T):
+        for k in range(topk):
+            e = int(ids[t, k])
+            a = (torch.nn.functional.silu(x[t].float() @ Wg[e].float().t()) * (x[t].float() @ Wu[e].float().t()))
+            want[t] += w[t, k] * (a.to(torch.bfloat16).float() @ Wd[e].float().t())
+    assert rel_err(cpu, want) < 1.5e-2
+    assert rel_err(gpu, want) < 1.5e-2
