@@ -1,0 +1,208 @@
+#!/usr/bin/env python3
+"""Headline benchmark: consensus answers/sec and p50 latency on one MI355X node.
+
+Workload A (the timed "step"): a heterogeneous 3-model ensemble (Llama-3-8B, Qwen2.5-7B,
+Mistral-7B shapes, bf16, random-init weights) answers a batch of synthetic
+multiple-choice questions; every member prefills the prompt, samples a fixed-length
+answer with top-p/temperature, decides its choice by on-device log-probs at the last
+position, and the votes are reduced by the majority-vote kernel. One step = one batch of
+``--questions`` questions per GPU through the whole pipeline (tokenize -> 3x generate ->
+vote -> cross-GPU gather of the results over RCCL).
+
+Workload B (reported alongside, same run): Llama-3-8B self-consistency with K=16 sampled
+chains per question forked from one prefill (shared-prefix paged KV), answer vote.
+
+Scaling is weak: every GPU hosts a full ensemble replica (47 GB of weights fit easily in
+288 GB) and serves its own shard of the questions; ranks only exchange results.
+
+Launch: ``python bench.py`` (1 GPU) or
+``python -m torch.distributed.run --nproc-per-node N bench.py --gpus N``.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent
+if str(ROOT) not in sys.path:
+    sys.path.insert(0, str(ROOT))
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+REFERENCE_BOUND_ANSWERS_PER_S = 0.2  # derived upper bound for the reference (it publishes no numbers)
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--models", default="llama-3-8b,qwen2.5-7b,mistral-7b")
+    ap.add_argument("--questions", type=int, default=64, help="questions per GPU per step (workload A)")
+    ap.add_argument("--prompt-len", type=int, default=512)
+    ap.add_argument("--new-tokens", type=int, default=64)
+    ap.add_argument("--k-chains", type=int, default=16)
+    ap.add_argument("--sc-questions", type=int, default=16, help="questions per GPU per step (workload B)")
+    ap.add_argument("--sc-steps", type=int, default=None, help="timed steps of workload B (default: --steps)")
+    ap.add_argument("--skip-self-consistency", action="store_true")
+    ap.add_argument("--temperature", type=float, default=0.8)
+    ap.add_argument("--top-p", type=float, default=0.95)
+    ap.add_argument("--no-graphs", action="store_true")
+    ap.add_argument("--out", default=None, help="also write the JSON line to this file")
+    return ap.parse_args()
+
+
+def make_questions(rng: np.random.Generator, n: int, prompt_len: int):
+    """Synthetic multiple-choice prompts of exactly prompt_len tokens under the byte-level
+    tokenizer (BOS + prompt_len-1 printable ASCII bytes)."""
+    tail = "\nA. first B. second C. third D. fourth\nAnswer:"
+    body = prompt_len - 1 - len(tail)
+    qs = []
+    for _ in range(n):
+        chars = rng.integers(97, 123, size=body)
+        chars[rng.integers(0, body, size=body // 6)] = 32
+        qs.append(bytes(chars.astype(np.uint8)).decode("ascii") + tail)
+    return qs
+
+
+def main() -> None:
+    a = parse_args()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (torch.cuda.is_available() is False)")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist  # type: ignore
+
+        dist.init_process_group("nccl", device_id=dev)
+
+    from llm_consensus_amd._native import core
+    from llm_consensus_amd.consensus.backend import GenParams
+    from llm_consensus_amd.consensus.members import Member
+    from llm_consensus_amd.consensus.strategies import MajorityVote, SelfConsistency
+    from llm_consensus_amd.engine.backend import EngineBackend
+    from llm_consensus_amd.engine.engine import Engine
+    from llm_consensus_amd.models.config import get_preset
+    from llm_consensus_amd.models.transformer import TransformerModel
+    from llm_consensus_amd.parallel.comm import make_comm
+    from llm_consensus_amd.utils.tokenizer import ByteLevelTokenizer
+
+    comm = make_comm(dist, dev)
+    names = [n.strip() for n in a.models.split(",") if n.strip()]
+    bs = 64
+    seq_len = a.prompt_len + a.new_tokens
+    blocks_per_seq = (seq_len + bs - 1) // bs + 1
+    max_seqs = max(a.questions, a.sc_questions * a.k_chains)
+    t_init = time.perf_counter()
+    members = []
+    personas = core.default_personas()
+    for i, name in enumerate(names):
+        cfg = get_preset(name)
+        model = TransformerModel.random_init(cfg, dev, seed=1234 + i)
+        n_blocks = (max_seqs + 8) * blocks_per_seq + 64
+        eng = Engine(model, num_kv_blocks=n_blocks, block_size=bs, max_batch_seqs=max(256, max_seqs),
+                     max_prefill_tokens=8192, max_model_len=seq_len + 64, use_graphs=not a.no_graphs, name=name)
+        be = EngineBackend(eng, ByteLevelTokenizer(cfg.vocab_size), stop_at_eos=False)
+        gp = GenParams(temperature=a.temperature, top_p=a.top_p, max_new_tokens=a.new_tokens, seed=17 * i)
+        members.append(Member(personas[i % len(personas)], be, params=gp))
+    torch.cuda.synchronize()
+    init_s = time.perf_counter() - t_init
+
+    vote = MajorityVote(members, choices="ABCD", decision_mode="logprob", device=dev)
+    sc = SelfConsistency(members[0], k_chains=a.k_chains, choices="ABCD", decision_mode="logprob", device=dev)
+    rng = np.random.default_rng(1000 + rank)
+
+    def gather_answers(results):
+        """X4: cross-GPU gather of the per-question winners (class ids) to every rank."""
+        w = torch.tensor([("ABCD".find(r.answer) if r.answer else -1) for r in results], dtype=torch.int32, device=dev)
+        return comm.all_gather_rows(w)
+
+    def run_phase(strategy, n_q, steps, warmup):
+        lat = []
+        for _ in range(warmup):
+            gather_answers(strategy.ask_many(make_questions(rng, n_q, a.prompt_len)))
+        comm.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        n_ans = 0
+        for _ in range(steps):
+            res = strategy.ask_many(make_questions(rng, n_q, a.prompt_len))
+            allw = gather_answers(res)
+            n_ans += int(allw.numel())
+            lat += [r.latency_s * 1e3 for r in res]
+        torch.cuda.synchronize()
+        comm.barrier()
+        el = comm.max_float(time.perf_counter() - t0)
+        return el, n_ans, lat
+
+    el_a, n_a, lat_a = run_phase(vote, a.questions, a.steps, a.warmup)
+    lat_all = comm.gather_floats(lat_a)
+    out = {
+        "metric": "consensus answers/sec (node), 3x7-8B majority-vote ensemble",
+        "value": round(n_a / el_a, 3),
+        "unit": "answers/s",
+        "n_gpus": world,
+        "steps": a.steps,
+        "warmup": a.warmup,
+        "ms_per_step": round(el_a / a.steps * 1e3, 2),
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": round(n_a / el_a / REFERENCE_BOUND_ANSWERS_PER_S, 1),
+        "baseline_note": "reference publishes no numbers; ratio is against its derived bound of 0.2 answers/s",
+        "dtype": "bf16",
+        "data": "synthetic prompts, random-init weights",
+        "p50_latency_ms": round(float(np.percentile(lat_all, 50)), 1),
+        "p95_latency_ms": round(float(np.percentile(lat_all, 95)), 1),
+        "config": {
+            "model": "+".join(names),
+            "global_batch": a.questions * world,
+            "seq_len": seq_len,
+            "prompt_len": a.prompt_len,
+            "new_tokens": a.new_tokens,
+            "sampling": {"temperature": a.temperature, "top_p": a.top_p},
+            "reducer": "majority_vote (logprob-decided choices, device kernel)",
+            "parallelism": f"dp{world} (one full ensemble replica per GPU)",
+            "decode": "hipGraph" if not a.no_graphs else "eager",
+        },
+        "init_s": round(init_s, 1),
+    }
+    if not a.skip_self_consistency:
+        steps_b = a.sc_steps or a.steps
+        el_b, n_b, lat_b = run_phase(sc, a.sc_questions, steps_b, a.warmup)
+        lat_b_all = comm.gather_floats(lat_b)
+        st = members[0].backend.stats()
+        out["self_consistency"] = {
+            "metric": f"consensus answers/sec, {names[0]} K={a.k_chains} self-consistency",
+            "value": round(n_b / el_b, 3),
+            "ms_per_step": round(el_b / steps_b * 1e3, 2),
+            "steps": steps_b,
+            "questions_per_gpu": a.sc_questions,
+            "p50_latency_ms": round(float(np.percentile(lat_b_all, 50)), 1),
+            "p95_latency_ms": round(float(np.percentile(lat_b_all, 95)), 1),
+            "chains_tokens_per_s": round(n_b * a.k_chains * a.new_tokens / el_b, 1),
+            "prefix_cache_hit_rate": round(float(st.get("kv.prefix_hit_rate", 0.0)), 3),
+            "cow_copies": int(st.get("kv.cow_copies_total", 0)),
+        }
+    if rank == 0:
+        line = json.dumps(out)
+        print(line, flush=True)
+        if a.out:
+            Path(a.out).parent.mkdir(parents=True, exist_ok=True)
+            Path(a.out).write_text(line + "\n")
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

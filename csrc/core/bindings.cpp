@@ -201,11 +201,12 @@ PYBIND11_MODULE(_core, m) {
       .def(py::init<int, int, bool>(), py::arg("num_blocks"), py::arg("block_size"),
            py::arg("enable_prefix_cache") = true)
       .def("create_sequence",
-           [](KVManager& kv, i32arr tokens) {
+           [](KVManager& kv, i32arr tokens, bool allow_cache_hit) {
              int cached = 0;
-             int id = kv.create_sequence(tokens.data(), static_cast<int>(tokens.size()), &cached);
+             int id = kv.create_sequence(tokens.data(), static_cast<int>(tokens.size()), &cached, allow_cache_hit);
              return py::make_tuple(id, cached);
-           })
+           },
+           py::arg("tokens"), py::arg("allow_cache_hit") = true)
       .def("reserve", &KVManager::reserve)
       .def("commit", [](KVManager& kv, int seq, i32arr tokens) {
         kv.commit(seq, tokens.data(), static_cast<int>(tokens.size()));

@@ -80,11 +80,11 @@ int KVManager::alloc_or_evict() {
   return -1;
 }
 
-int KVManager::create_sequence(const int32_t* tokens, int n, int* cached_tokens) {
+int KVManager::create_sequence(const int32_t* tokens, int n, int* cached_tokens, bool allow_cache_hit) {
   if (n <= 0) throw std::invalid_argument("KVManager::create_sequence: empty prompt");
   Seq s;
   int matched = 0;
-  if (prefix_cache_) {
+  if (prefix_cache_ && allow_cache_hit) {
     // At least one token must be left to run so the step produces logits.
     int max_match = (n - 1) / block_size_;
     uint64_t prev = 0;

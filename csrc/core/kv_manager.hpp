@@ -53,7 +53,9 @@ class KVManager {
   // prefix cache are attached by reference. Returns the sequence id, or -1 if
   // blocks for the rest of the prompt cannot be allocated (nothing is leaked).
   // *cached_tokens receives how many leading tokens already have KV.
-  int create_sequence(const int32_t* tokens, int n, int* cached_tokens);
+  // `allow_cache_hit=false` forces every token to be recomputed (requests that need the
+  // hidden state of every prompt token, e.g. embeddings).
+  int create_sequence(const int32_t* tokens, int n, int* cached_tokens, bool allow_cache_hit = true);
 
   // Ensures the sequence has room for `n_new` more tokens, allocating blocks and
   // queueing a copy-on-write if its partially filled tail block is shared.

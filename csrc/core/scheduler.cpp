@@ -60,7 +60,8 @@ bool Scheduler::try_admit(Group& g) {
   if (promised + g.n > cfg_.max_batch_seqs) return false;
   if (budget_used_ + g.budget_blocks > kv_->stats().blocks_total) return false;
   int cached = 0;
-  int seq = kv_->create_sequence(g.prompt.data(), static_cast<int>(g.prompt.size()), &cached);
+  int seq = kv_->create_sequence(g.prompt.data(), static_cast<int>(g.prompt.size()), &cached,
+                                 g.kind != RequestKind::Embed);
   if (seq < 0) return false;
   g.cached = cached;
   g.computed = cached;

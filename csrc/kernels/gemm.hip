@@ -283,7 +283,8 @@ __global__ __launch_bounds__(256) void wsgemm_kernel(const bf16_t* __restrict__ 
   const int KT = K / 32;
   const int nt0 = (blockIdx.x * 4 + wave) * NTW;
   const int kt_begin = blockIdx.y * kt_per_split;
-  const int iters = kt_per_split / KPI;
+  const int kt_end = kt_begin + kt_per_split;
+  const int iters = (kt_per_split + KPI - 1) / KPI;  // the last iteration may be partial
 
   auto stage_x = [&](char* stage, int kt0) {
     // MT*KPI pieces of 1 KiB, dealt round-robin to the 4 waves.
@@ -291,7 +292,9 @@ __global__ __launch_bounds__(256) void wsgemm_kernel(const bf16_t* __restrict__ 
       const int mt = p / KPI, kt = p % KPI;
       int row = mt * 16 + (lane & 15);
       row = row < M ? row : M - 1;
-      const bf16_t* src = X + static_cast<size_t>(row) * K + (kt0 + kt) * 32 + 8 * (lane >> 4);
+      // k-tiles past the split's end are clamped: their weights are zero, X only has to be finite
+      const int ktc = kt0 + kt < kt_end ? kt0 + kt : kt_end - 1;
+      const bf16_t* src = X + static_cast<size_t>(row) * K + ktc * 32 + 8 * (lane >> 4);
       __builtin_amdgcn_global_load_lds(LC_GLOBAL_PTR(src), LC_LDS_PTR(stage + p * 1024), 16, 0, 0);
     }
   };
@@ -299,9 +302,13 @@ __global__ __launch_bounds__(256) void wsgemm_kernel(const bf16_t* __restrict__ 
 #pragma unroll
     for (int n = 0; n < NTW; ++n)
 #pragma unroll
-      for (int kt = 0; kt < KPI; ++kt)
-        w[n][kt] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(
-            Wp + (static_cast<size_t>(nt0 + n) * KT + (kt0 + kt)) * 512 + lane * 8));
+      for (int kt = 0; kt < KPI; ++kt) {
+        if (kt0 + kt < kt_end)
+          w[n][kt] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(
+              Wp + (static_cast<size_t>(nt0 + n) * KT + (kt0 + kt)) * 512 + lane * 8));
+        else
+          w[n][kt] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+      }
   };
 
   f32x4 acc[NTW][MT];
@@ -443,7 +450,7 @@ LC_EXPORT int lc_gemm_tile(const void* Wp, const void* X, void* Y, const void* b
 }
 
 // Weight-streaming GEMM for M <= 256. `splits` > 1 requires epi == EPI_F32 and Y = fp32
-// workspace of [splits, M, ldy]; follow with lc_splitk_reduce. (K/32) % (splits*KPI) == 0.
+// workspace of [splits, M, ldy]; follow with lc_splitk_reduce. (K/32) % splits == 0.
 LC_EXPORT int lc_wsgemm(const void* Wp, const void* X, void* Y, const void* bias, int M, int N, int K,
                         int n_pad, int ldy, int epi, int splits, hipStream_t stream) {
   if (M <= 0) return 0;
@@ -456,19 +463,19 @@ LC_EXPORT int lc_wsgemm(const void* Wp, const void* X, void* Y, const void* bias
   const int mt = (M + 15) / 16;
   // KPI (k-tiles per iteration) shrinks as M grows so one X stage stays <= 32 KiB.
   if (mt <= 1) {
-    if (kt % (splits * 8)) return -1;
+    if (kt % splits) return -1;
     return launch_ws<1, 2, 8>(epi, w, x, Y, b, M, N, K, ldy, n_pad, splits, stream);
   } else if (mt <= 2) {
-    if (kt % (splits * 8)) return -1;
+    if (kt % splits) return -1;
     return launch_ws<2, 2, 8>(epi, w, x, Y, b, M, N, K, ldy, n_pad, splits, stream);
   } else if (mt <= 4) {
-    if (kt % (splits * 8)) return -1;
+    if (kt % splits) return -1;
     return launch_ws<4, 2, 8>(epi, w, x, Y, b, M, N, K, ldy, n_pad, splits, stream);
   } else if (mt <= 8) {
-    if (kt % (splits * 4)) return -1;
+    if (kt % splits) return -1;
     return launch_ws<8, 2, 4>(epi, w, x, Y, b, M, N, K, ldy, n_pad, splits, stream);
   } else {
-    if (kt % (splits * 2)) return -1;
+    if (kt % splits) return -1;
     return launch_ws<16, 2, 2>(epi, w, x, Y, b, M, N, K, ldy, n_pad, splits, stream);
   }
 }

@@ -130,7 +130,6 @@ __global__ __launch_bounds__(kThreads) void sample_kernel(
       float m, c;
       mass_above(row, V, inv_t, zmax, mid, red, &m, &c);
       if (m >= target) {
-        if (c == c_lo) { lo = mid; break; }  // same kept set: converged
         lo = mid;
         m_lo = m;
         c_lo = c;

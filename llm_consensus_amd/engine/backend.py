@@ -1,0 +1,99 @@
+"""``EngineBackend``: the text-level Backend over an in-process Engine.
+
+This is the drop-in for the reference's ``call_gemini`` (/root/reference/src/main.rs:82-86)
+that members talk to: prompts are tokenized, queued on the engine and completed by
+``run()``, which steps the engine until every queued request has finished. Several
+members (personas) share one EngineBackend when they share a model, so their requests
+batch together and their common prompt prefixes are served from the prefix cache.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional, Sequence
+
+from .._native import core
+from ..consensus.backend import Backend, BackendError, GenParams, GenResult, Handle
+from ..utils.tokenizer import Tokenizer
+from .engine import Engine
+
+
+class EngineBackend(Backend):
+    def __init__(self, engine: Engine, tokenizer: Tokenizer, name: Optional[str] = None,
+                 stop_at_eos: bool = True) -> None:
+        self.engine, self.tok = engine, tokenizer
+        self.name = name or engine.name
+        self.stop_at_eos = stop_at_eos
+        self._pending: Dict[int, tuple] = {}
+
+    def _params(self, p: GenParams) -> "core.SamplingParams":
+        sp = core.SamplingParams()
+        sp.temperature, sp.top_p, sp.top_k = p.temperature, p.top_p, p.top_k
+        sp.max_new_tokens, sp.seed = p.max_new_tokens, p.seed
+        if self.stop_at_eos and self.tok.eos_id is not None:
+            sp.eos_id = self.tok.eos_id
+        else:
+            sp.ignore_eos = True
+        return sp
+
+    def submit_generate(self, prompt: str, params: GenParams) -> Handle:
+        h = Handle()
+        try:
+            ids = self.tok.encode(prompt)
+            dec = [self.tok.first_token_id(t) for t in params.decision_targets] if params.decision_targets else None
+            rid = self.engine.submit(ids, core.RequestKind.Generate, max(1, params.n), self._params(params), dec)
+            self._pending[rid] = ("gen", h)
+        except Exception as e:  # a bad request fails that member only
+            h.set_error(e)
+        return h
+
+    def submit_score(self, prompt: str, targets: Sequence[str]) -> Handle:
+        h = Handle()
+        try:
+            ids = self.tok.encode(prompt)
+            tids = [self.tok.first_token_id(t) for t in targets]
+            rid = self.engine.submit(ids, core.RequestKind.Score, score_ids=tids)
+            self._pending[rid] = ("score", h)
+        except Exception as e:
+            h.set_error(e)
+        return h
+
+    def submit_embed(self, text: str) -> Handle:
+        h = Handle()
+        try:
+            rid = self.engine.submit(self.tok.encode(text), core.RequestKind.Embed)
+            self._pending[rid] = ("embed", h)
+        except Exception as e:
+            h.set_error(e)
+        return h
+
+    def run(self) -> None:
+        try:
+            self.engine.run_until_done()
+        except Exception as e:
+            for rid, (_, h) in self._pending.items():
+                if not h.done:
+                    h.set_error(BackendError(f"engine failure: {e}"))
+            self._pending.clear()
+            raise
+        for rid, (kind, h) in list(self._pending.items()):
+            out = self.engine.pop_result(rid)
+            if out is None:
+                h.set_error(BackendError("request did not finish"))
+                continue
+            if kind == "gen":
+                eos = self.tok.eos_id
+                texts = []
+                for toks in out.token_ids:
+                    if eos is not None and toks and toks[-1] == eos:
+                        toks = toks[:-1]
+                    texts.append(self.tok.decode(toks))
+                h.set_result(GenResult(texts=texts, token_ids=out.token_ids, cum_logprobs=out.cum_logprobs,
+                                       decision_logprobs=out.decision_logprobs, prompt_tokens=out.prompt_len,
+                                       cached_tokens=out.cached_tokens))
+            elif kind == "score":
+                h.set_result(out.scores)
+            else:
+                h.set_result(out.embedding)
+        self._pending.clear()
+
+    def stats(self) -> Dict[str, float]:
+        return self.engine.stats()

@@ -1,0 +1,370 @@
+"""Member engine: one model on one device (or TP group), served with paged KV,
+continuous batching, forked sequence groups and hipGraph-captured decode steps.
+
+This is what replaces the reference's ``call_gemini`` (/root/reference/src/main.rs:82-86):
+instead of one HTTPS round trip per message, requests from every consensus session
+and persona that shares this model are queued (``submit``), batched by the native
+scheduler (csrc/core/scheduler.cpp) and advanced together (``step``). The host only
+moves small int32 arrays per step; tokens are sampled on device.
+"""
+from __future__ import annotations
+
+import time
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Sequence
+
+import numpy as np
+import torch
+
+from .. import ops
+from .._native import core
+from ..models.transformer import AttnMeta, KVCache, TransformerModel
+from ..utils.log import get_logger
+
+log = get_logger("consensus.engine")
+PK = core.StepPlan.Kind
+
+
+@dataclass
+class RequestOutput:
+    request_id: int
+    kind: "core.RequestKind"
+    token_ids: List[List[int]] = field(default_factory=list)        # per chain
+    cum_logprobs: List[float] = field(default_factory=list)
+    finish_reasons: List[str] = field(default_factory=list)
+    decision_logprobs: Optional[List[List[float]]] = None            # [chain][target]
+    scores: Optional[List[float]] = None                             # Score requests
+    embedding: Optional[np.ndarray] = None                           # Embed requests
+    prompt_len: int = 0
+    cached_tokens: int = 0
+    submitted_at: float = 0.0
+    finished_at: float = 0.0
+
+
+@dataclass
+class _ReqState:
+    kind: "core.RequestKind"
+    n: int
+    decision_ids: Optional[List[int]] = None
+    score_ids: Optional[List[int]] = None
+    decisions: Dict[int, List[float]] = field(default_factory=dict)  # chain seed -> latest decision log-probs
+    scores: Optional[List[float]] = None
+    embed_sum: Optional[torch.Tensor] = None
+    embed_count: int = 0
+    seed: int = 0
+    submitted_at: float = 0.0
+
+
+class _DecodeGraph:
+    """Static buffers + captured graph of one decode step for a batch bucket."""
+
+    def __init__(self, eng: "Engine", bucket: int, with_prefix: bool) -> None:
+        dev = eng.device
+        i32 = dict(dtype=torch.int32, device=dev)
+        self.bucket, self.with_prefix = bucket, with_prefix
+        self.token_ids = torch.zeros(bucket, **i32)
+        self.positions = torch.zeros(bucket, **i32)
+        self.slot_mapping = torch.full((bucket,), -1, **i32)
+        self.block_tables = torch.zeros(bucket, eng.max_blocks_cap, **i32)
+        self.ctx_lens = torch.zeros(bucket, **i32)
+        self.temperature = torch.zeros(bucket, dtype=torch.float32, device=dev)
+        self.top_p = torch.ones(bucket, dtype=torch.float32, device=dev)
+        self.top_k = torch.zeros(bucket, **i32)
+        self.seeds = torch.zeros(bucket, dtype=torch.int64, device=dev)
+        self.steps = torch.zeros(bucket, **i32)
+        self.decision_ids = torch.zeros(bucket, eng.max_decision, **i32)
+        self.gmax = max(1, bucket // 2)
+        self.group_first = torch.zeros(self.gmax, **i32)
+        self.group_count = torch.zeros(self.gmax, **i32)
+        self.group_shared = torch.zeros(self.gmax, **i32)
+        self.kv_begin = torch.zeros(bucket, **i32)
+        self.nsplit = ops.choose_kv_splits(bucket, eng.model.hkv, eng.nominal_ctx)
+        self.prefix_splits = max(1, min(8, 1024 // max(1, self.gmax * eng.model.hkv)))
+        self.graph: Optional[torch.cuda.CUDAGraph] = None
+        self.out_tokens = self.out_lps = self.out_dec = None
+
+    def meta(self, eng: "Engine") -> AttnMeta:
+        return AttnMeta(
+            is_prefill=False, block_tables=self.block_tables, ctx_lens=self.ctx_lens, nsplit=self.nsplit,
+            groups=(self.group_first, self.group_count, self.group_shared) if self.with_prefix else None,
+            kv_begin=self.kv_begin if self.with_prefix else None,
+            max_group_rows=eng.max_group_rows if self.with_prefix else 0, prefix_splits=self.prefix_splits)
+
+    def run_body(self, eng: "Engine"):
+        hidden = eng.model.forward(self.token_ids, self.positions, self.slot_mapping, self.meta(eng), eng.kv)
+        logits = eng.model.logits(hidden)
+        tok, lp = ops.sample(logits, self.temperature, self.top_p, self.top_k, self.seeds, self.steps)
+        dec = ops.logprob_gather(logits, self.decision_ids)
+        return tok, lp, dec
+
+    def capture(self, eng: "Engine") -> None:
+        # warm-up on a side stream (allocator + lazy init), then capture
+        s = torch.cuda.Stream(device=eng.device)
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            self.run_body(eng)
+        torch.cuda.current_stream().wait_stream(s)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, pool=eng.graph_pool):
+            self.out_tokens, self.out_lps, self.out_dec = self.run_body(eng)
+        self.graph = g
+        if eng.graph_pool is None:
+            eng.graph_pool = g.pool()
+
+
+class Engine:
+    def __init__(self, model: TransformerModel, num_kv_blocks: Optional[int] = None, block_size: int = 64,
+                 max_batch_seqs: int = 256, max_prefill_tokens: int = 8192, max_model_len: int = 4096,
+                 kv_fraction: float = 0.6, enable_prefix_cache: bool = True, use_graphs: Optional[bool] = None,
+                 graph_buckets: Sequence[int] = (1, 2, 4, 8, 16, 32, 64, 128, 256), max_decision: int = 8,
+                 max_group_rows: int = 16, name: str = "engine") -> None:
+        self.model, self.device, self.name = model, model.device, name
+        cfg = model.cfg
+        self.block_size = block_size
+        self.max_model_len = min(max_model_len, cfg.max_position)
+        if num_kv_blocks is None:
+            per_block = KVCache.bytes_per_block(cfg, block_size, model.hkv)
+            if self.device.type == "cuda":
+                free, _ = torch.cuda.mem_get_info(self.device)
+                num_kv_blocks = max(16, int(free * kv_fraction) // per_block)
+            else:
+                num_kv_blocks = 256
+        self.kv = KVCache(cfg, num_kv_blocks, block_size, self.device, model.hkv)
+        self.kvm = core.KVManager(num_kv_blocks, block_size, enable_prefix_cache)
+        sc = core.SchedulerConfig()
+        sc.max_batch_seqs, sc.max_prefill_tokens = max_batch_seqs, max_prefill_tokens
+        self.sched = core.Scheduler(self.kvm, sc)
+        self.max_batch_seqs = max_batch_seqs
+        self.max_blocks_cap = (self.max_model_len + block_size - 1) // block_size + 1
+        self.nominal_ctx = min(self.max_model_len, 1024)
+        self.max_decision = max_decision
+        self.max_group_rows = max_group_rows
+        self.use_graphs = (self.device.type == "cuda") if use_graphs is None else (use_graphs and self.device.type == "cuda")
+        self.graph_buckets = sorted(b for b in graph_buckets if b <= max_batch_seqs) or [max_batch_seqs]
+        self.graph_pool = None
+        self._graphs: Dict[tuple, _DecodeGraph] = {}
+        self._reqs: Dict[int, _ReqState] = {}
+        self._done: Dict[int, RequestOutput] = {}
+        self.metrics = core.Metrics()
+
+    # ------------------------------------------------------------------ submission
+    def submit(self, prompt_ids: Sequence[int], kind: "core.RequestKind" = core.RequestKind.Generate, n: int = 1,
+               params: Optional["core.SamplingParams"] = None, decision_ids: Optional[Sequence[int]] = None,
+               score_ids: Optional[Sequence[int]] = None) -> int:
+        p = params or core.SamplingParams()
+        ids = np.asarray(prompt_ids, dtype=np.int32)
+        if ids.size == 0:
+            raise ValueError("empty prompt")
+        budget = self.max_model_len - (p.max_new_tokens if kind == core.RequestKind.Generate else 0)
+        if ids.size > budget:
+            ids = ids[-budget:]  # keep the tail (the instructions and the answer slot are at the end)
+        if decision_ids is not None and len(decision_ids) > self.max_decision:
+            raise ValueError(f"at most {self.max_decision} decision targets")
+        rid = self.sched.add_request(kind, ids, n, p)
+        self._reqs[rid] = _ReqState(kind, n if kind == core.RequestKind.Generate else 1,
+                                    list(decision_ids) if decision_ids is not None else None,
+                                    list(score_ids) if score_ids is not None else None, seed=p.seed,
+                                    submitted_at=time.perf_counter())
+        return rid
+
+    def has_work(self) -> bool:
+        return self.sched.has_work()
+
+    def pop_result(self, rid: int) -> Optional[RequestOutput]:
+        return self._done.pop(rid, None)
+
+    def run_until_done(self) -> None:
+        while self.step():
+            pass
+
+    # ------------------------------------------------------------------ stepping
+    def _dev(self, a: np.ndarray, dtype=torch.int32) -> torch.Tensor:
+        return torch.from_numpy(np.ascontiguousarray(a)).to(device=self.device, dtype=dtype, non_blocking=True)
+
+    def step(self) -> bool:
+        plan = self.sched.schedule()
+        if plan.kind == PK.Idle:
+            return False
+        if len(plan.copy_src):
+            self.kv.copy_blocks(self._dev(plan.copy_src), self._dev(plan.copy_dst))
+            self.metrics.inc("kv.cow_copies", len(plan.copy_src))
+        t0 = time.perf_counter()
+        if plan.kind == PK.Prefill:
+            self._prefill(plan)
+            self.metrics.inc("prefill.steps")
+            self.metrics.inc("prefill.tokens", len(plan.token_ids))
+            self.metrics.inc("prefill.seconds", time.perf_counter() - t0)
+        else:
+            self._decode(plan)
+            self.metrics.inc("decode.steps")
+            self.metrics.inc("decode.tokens", len(plan.seq_ids))
+            self.metrics.inc("decode.seconds", time.perf_counter() - t0)
+        self._collect()
+        return True
+
+    def _prefill(self, plan) -> None:
+        m = self.model
+        tok = self._dev(plan.token_ids)
+        meta = AttnMeta(is_prefill=True, block_tables=self._dev(plan.block_tables), ctx_lens=self._dev(plan.context_lens),
+                        cu_q=self._dev(plan.cu_q), max_q_len=int(np.diff(plan.cu_q).max()))
+        hidden = m.forward(tok, self._dev(plan.positions), self._dev(plan.slot_mapping), meta, self.kv)
+        req_ids = plan.request_ids
+        # Embed requests: accumulate the sum of this chunk's final hidden states.
+        cu = plan.cu_q
+        for i, rid in enumerate(req_ids):
+            st = self._reqs[int(rid)]
+            if st.kind == core.RequestKind.Embed:
+                rows = hidden[int(cu[i]):int(cu[i + 1])].float()
+                s = rows.sum(0)
+                st.embed_sum = s if st.embed_sum is None else st.embed_sum + s
+                st.embed_count += rows.shape[0]
+        first_tokens = np.zeros(0, dtype=np.int32)
+        first_lps = np.zeros(0, dtype=np.float32)
+        if len(plan.last_rows):
+            rows = hidden[self._dev(plan.last_rows, torch.int64)]
+            logits = m.logits(rows)
+            slots = self.sched.prefill_sample_layout(plan)
+            if slots:
+                ri = self._dev(np.array([s.last_row_index for s in slots], dtype=np.int32))
+                toks, lps = ops.sample(
+                    logits,
+                    self._dev(np.array([s.temperature for s in slots], dtype=np.float32), torch.float32),
+                    self._dev(np.array([s.top_p for s in slots], dtype=np.float32), torch.float32),
+                    self._dev(np.array([s.top_k for s in slots], dtype=np.int32)),
+                    self._dev(np.array([s.seed for s in slots], dtype=np.int64), torch.int64),
+                    self._dev(np.zeros(len(slots), dtype=np.int32)), ri)
+                first_tokens, first_lps = toks.cpu().numpy(), lps.cpu().numpy()
+            # decisions / scores at the prompt's last position
+            for j, seq_i in enumerate(plan.last_row_seq):
+                rid = int(req_ids[int(seq_i)])
+                st = self._reqs[rid]
+                row = torch.tensor([j], dtype=torch.int32, device=self.device)
+                if st.kind == core.RequestKind.Score and st.score_ids:
+                    ids = torch.tensor(st.score_ids, dtype=torch.int32, device=self.device)
+                    st.scores = ops.logprob_gather(logits, ids, row)[0].cpu().tolist()
+                elif st.kind == core.RequestKind.Generate and st.decision_ids:
+                    ids = torch.tensor(st.decision_ids, dtype=torch.int32, device=self.device)
+                    d = ops.logprob_gather(logits, ids, row)[0].cpu().tolist()
+                    for k in range(st.n):
+                        st.decisions[st.seed + k] = d
+        self.sched.complete_prefill(plan, first_tokens.astype(np.int32), first_lps.astype(np.float32))
+
+    def _bucket(self, B: int) -> int:
+        for b in self.graph_buckets:
+            if b >= B:
+                return b
+        return B
+
+    def _decode(self, plan) -> None:
+        B = len(plan.seq_ids)
+        gshared = plan.group_shared_blocks
+        gcount = plan.group_count
+        with_prefix = bool(len(gshared)) and bool(((gshared > 0) & (gcount > 1)).any()) and \
+            int(gcount.max()) <= self.max_group_rows
+        bucket = self._bucket(B) if self.use_graphs else B
+        key = (bucket, with_prefix)
+        g = self._graphs.get(key)
+        if g is None:
+            g = _DecodeGraph(self, bucket, with_prefix)
+            if not self.use_graphs:
+                g.nsplit = 1 if self.device.type != "cuda" else g.nsplit
+            self._graphs[key] = g
+        # ---- fill static inputs ----
+        def put(dst: torch.Tensor, a: np.ndarray, fill=0):
+            n = a.shape[0]
+            dst[:n].copy_(torch.from_numpy(np.ascontiguousarray(a)).to(dst.dtype), non_blocking=True)
+            if n < dst.shape[0]:
+                dst[n:].fill_(fill)
+
+        put(g.token_ids, plan.token_ids)
+        put(g.positions, plan.positions)
+        put(g.slot_mapping, plan.slot_mapping, -1)
+        put(g.ctx_lens, plan.context_lens)
+        bt = plan.block_tables
+        g.block_tables[:B, : bt.shape[1]].copy_(torch.from_numpy(np.maximum(bt, 0)), non_blocking=True)
+        req_ids = plan.request_ids
+        temp = np.zeros(B, np.float32); top_p = np.ones(B, np.float32); top_k = np.zeros(B, np.int32)
+        dec = np.zeros((B, self.max_decision), np.int32)
+        cache: Dict[int, tuple] = {}
+        for b in range(B):
+            rid = int(req_ids[b])
+            e = cache.get(rid)
+            if e is None:
+                p = self.sched.params_of(rid)
+                d = self._reqs[rid].decision_ids
+                e = (p.temperature, p.top_p, p.top_k, d)
+                cache[rid] = e
+            temp[b], top_p[b], top_k[b] = e[0], e[1], e[2]
+            if e[3]:
+                dec[b, : len(e[3])] = e[3]
+        put(g.temperature, temp)
+        put(g.top_p, top_p, 1)
+        put(g.top_k, top_k)
+        put(g.seeds, plan.seeds.astype(np.int64))
+        put(g.steps, plan.step_index)
+        g.decision_ids[:B].copy_(torch.from_numpy(dec), non_blocking=True)
+        if with_prefix:
+            ng = len(gcount)
+            if ng > g.gmax:
+                raise RuntimeError("more sequence groups than the decode graph was sized for")
+            put(g.group_first, plan.group_first)
+            put(g.group_count, np.where(gshared > 0, gcount, 0).astype(np.int32))
+            put(g.group_shared, gshared)
+            kvb = np.zeros(B, np.int32)
+            for gi in range(ng):
+                if gshared[gi] > 0 and gcount[gi] > 1:
+                    f, c = int(plan.group_first[gi]), int(gcount[gi])
+                    kvb[f:f + c] = int(gshared[gi]) * self.block_size
+            put(g.kv_begin, kvb)
+        # ---- run ----
+        if self.use_graphs:
+            if g.graph is None:
+                g.capture(self)
+            g.graph.replay()
+            tok, lp, dl = g.out_tokens, g.out_lps, g.out_dec
+        else:
+            tok, lp, dl = g.run_body(self)
+        tok_h = tok[:B].cpu().numpy()
+        lp_h = lp[:B].cpu().numpy()
+        if any(e[3] for e in cache.values()):
+            dl_h = dl[:B].cpu().numpy()
+            for b in range(B):
+                st = self._reqs[int(req_ids[b])]
+                if st.decision_ids:
+                    st.decisions[int(plan.seeds[b])] = dl_h[b, : len(st.decision_ids)].tolist()
+        self.sched.complete_decode(plan, tok_h.astype(np.int32), lp_h.astype(np.float32))
+
+    def _collect(self) -> None:
+        for f in self.sched.take_finished():
+            st = self._reqs.pop(f.request_id)
+            out = RequestOutput(f.request_id, f.kind, prompt_len=f.prompt_len, cached_tokens=f.cached_tokens,
+                                submitted_at=st.submitted_at, finished_at=time.perf_counter())
+            for c in f.chains:
+                out.token_ids.append(list(c.tokens))
+                out.cum_logprobs.append(c.cum_logprob)
+                out.finish_reasons.append(c.reason.name)
+            if st.decision_ids:
+                out.decision_logprobs = [st.decisions.get(st.seed + k, [0.0] * len(st.decision_ids))
+                                         for k in range(len(f.chains))]
+            if st.kind == core.RequestKind.Score:
+                out.scores = st.scores
+            if st.kind == core.RequestKind.Embed and st.embed_sum is not None:
+                v = (st.embed_sum / max(1, st.embed_count))
+                out.embedding = (v / v.norm().clamp_min(1e-12)).cpu().numpy()
+            self._done[f.request_id] = out
+            self.metrics.inc("requests.finished")
+            self.metrics.observe("request.latency_ms", (out.finished_at - out.submitted_at) * 1e3)
+
+    # ------------------------------------------------------------------ introspection
+    def stats(self) -> Dict[str, float]:
+        s = dict(self.metrics.snapshot())
+        k = self.kvm.stats()
+        s.update({
+            "kv.blocks_total": k.blocks_total, "kv.blocks_free": k.blocks_free, "kv.blocks_cached": k.blocks_cached,
+            "kv.utilisation": 1.0 - k.blocks_free / max(1, k.blocks_total),
+            "kv.prompt_tokens": k.prompt_tokens, "kv.prefix_hit_tokens": k.prefix_hit_tokens,
+            "kv.prefix_hit_rate": k.prefix_hit_tokens / max(1, k.prompt_tokens),
+            "kv.cow_copies_total": k.cow_copies, "kv.evictions": k.evictions,
+        })
+        return s

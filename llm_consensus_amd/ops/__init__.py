@@ -101,7 +101,7 @@ def _choose_splits(n_pad: int, K: int, M: int, allow: bool) -> int:
     for s in (2, 3, 4, 6, 8, 12, 16):
         if blocks * best >= WS_TARGET_BLOCKS:
             break
-        if kt % (s * kpi) == 0 and kt // s >= 2 * kpi:
+        if kt % s == 0 and kt // s >= 2 * kpi:
             best = s
     return best
 

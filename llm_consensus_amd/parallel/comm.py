@@ -1,0 +1,231 @@
+"""Communication layer: one interface, RCCL in production, in-process loopback in tests.
+
+The reference's "communication" is actor messaging on one thread
+(/root/reference/src/main.rs:98, :144, :179, :234, :250-253, :282): point-to-point sends,
+a broadcast of (question, answer) to all members, a gather of N verdicts with a fan-in
+barrier (main.rs:265) and a logical AND over votes (main.rs:266). Hosting members on
+GPUs turns those into collectives, plus the tensor/expert-parallel collectives inside a
+model:
+
+    all_reduce        TP partial sums after attention-O and MLP-down (2 per layer)
+    all_gather_cols   vocab-parallel logits -> full logits
+    all_gather_rows   candidate answers / votes / log-probs / embeddings to every rank
+    broadcast         winning answer / next-round prompt
+    all_to_all_rows   expert-parallel token dispatch and combine
+
+``TorchDistComm`` runs them through ``torch.distributed`` (backend "nccl" is RCCL over
+xGMI on ROCm; "gloo" on CPU for tests). ``LoopbackComm`` implements the same calls over
+in-process buffers so every rank's shard can be run sequentially on one device and
+compared with the unsharded model.
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Sequence
+
+import torch
+
+
+class Comm:
+    rank: int = 0
+    world: int = 1
+
+    def all_reduce(self, t: torch.Tensor) -> torch.Tensor:
+        return t
+
+    def all_gather_cols(self, t: torch.Tensor, total_cols: Optional[int] = None) -> torch.Tensor:
+        return t
+
+    def all_gather_rows(self, t: torch.Tensor) -> torch.Tensor:
+        return t
+
+    def broadcast(self, t: torch.Tensor, src: int = 0) -> torch.Tensor:
+        return t
+
+    def all_to_all_rows(self, t: torch.Tensor, send_counts: Sequence[int], recv_counts: Sequence[int]) -> torch.Tensor:
+        return t
+
+    def barrier(self) -> None:
+        pass
+
+    def max_float(self, x: float) -> float:
+        return x
+
+    def gather_floats(self, xs: Sequence[float]) -> List[float]:
+        return list(xs)
+
+    def all_true(self, flag: bool) -> bool:
+        """Logical AND across ranks: the collective form of 'every member voted Good'."""
+        return flag
+
+
+class SingleComm(Comm):
+    pass
+
+
+class TorchDistComm(Comm):
+    def __init__(self, dist, device: torch.device, group=None) -> None:
+        self.dist, self.device, self.group = dist, device, group
+        self.rank = dist.get_rank(group)
+        self.world = dist.get_world_size(group)
+
+    def all_reduce(self, t: torch.Tensor) -> torch.Tensor:
+        self.dist.all_reduce(t, group=self.group)
+        return t
+
+    def all_gather_cols(self, t: torch.Tensor, total_cols: Optional[int] = None) -> torch.Tensor:
+        parts = [torch.empty_like(t) for _ in range(self.world)]
+        self.dist.all_gather(parts, t.contiguous(), group=self.group)
+        out = torch.cat(parts, dim=-1)
+        return out[..., :total_cols] if total_cols is not None else out
+
+    def all_gather_rows(self, t: torch.Tensor) -> torch.Tensor:
+        t = t.contiguous()
+        out = torch.empty((self.world * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+        self.dist.all_gather_into_tensor(out, t, group=self.group)
+        return out
+
+    def broadcast(self, t: torch.Tensor, src: int = 0) -> torch.Tensor:
+        self.dist.broadcast(t, src=src, group=self.group)
+        return t
+
+    def all_to_all_rows(self, t: torch.Tensor, send_counts: Sequence[int], recv_counts: Sequence[int]) -> torch.Tensor:
+        out = torch.empty((int(sum(recv_counts)),) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+        self.dist.all_to_all_single(out, t.contiguous(), list(map(int, recv_counts)), list(map(int, send_counts)),
+                                    group=self.group)
+        return out
+
+    def barrier(self) -> None:
+        self.dist.barrier(group=self.group)
+
+    def max_float(self, x: float) -> float:
+        t = torch.tensor([x], dtype=torch.float64, device=self.device)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX, group=self.group)
+        return float(t.item())
+
+    def gather_floats(self, xs: Sequence[float]) -> List[float]:
+        objs: List[Optional[list]] = [None] * self.world
+        self.dist.all_gather_object(objs, list(map(float, xs)), group=self.group)
+        return [x for part in objs for x in (part or [])]
+
+    def all_true(self, flag: bool) -> bool:
+        t = torch.tensor([1 if flag else 0], dtype=torch.int32, device=self.device)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MIN, group=self.group)
+        return bool(t.item())
+
+
+class LoopbackHub:
+    """Shared state of a set of LoopbackComm ranks that run as threads of one process
+    (all on one device): a barrier plus one slot per rank. Every collective is
+    deposit -> barrier -> combine -> barrier, so it is deterministic and needs no
+    second GPU. Used by the TP/EP tests to compare sharded and unsharded models."""
+
+    def __init__(self, world: int) -> None:
+        import threading
+
+        self.world = world
+        self.barrier = threading.Barrier(world)
+        self.slots: List[Optional[torch.Tensor]] = [None] * world
+        self.objs: List[object] = [None] * world
+
+
+class LoopbackComm(Comm):
+    def __init__(self, hub: LoopbackHub, rank: int) -> None:
+        self.hub, self.rank, self.world = hub, rank, hub.world
+
+    def _exchange(self, t: torch.Tensor) -> List[torch.Tensor]:
+        if t.is_cuda:
+            torch.cuda.synchronize()
+        self.hub.slots[self.rank] = t
+        self.hub.barrier.wait()
+        parts = [x.clone() for x in self.hub.slots]  # type: ignore[union-attr]
+        if t.is_cuda:
+            torch.cuda.synchronize()
+        self.hub.barrier.wait()
+        return parts
+
+    def all_reduce(self, t: torch.Tensor) -> torch.Tensor:
+        t.copy_(reduce_loopback(self._exchange(t)))
+        return t
+
+    def all_gather_cols(self, t: torch.Tensor, total_cols: Optional[int] = None) -> torch.Tensor:
+        out = torch.cat(self._exchange(t.contiguous()), dim=-1)
+        return out[..., :total_cols] if total_cols is not None else out
+
+    def all_gather_rows(self, t: torch.Tensor) -> torch.Tensor:
+        return torch.cat(self._exchange(t.contiguous()), dim=0)
+
+    def broadcast(self, t: torch.Tensor, src: int = 0) -> torch.Tensor:
+        t.copy_(self._exchange(t)[src])
+        return t
+
+    def all_to_all_rows(self, t: torch.Tensor, send_counts: Sequence[int], recv_counts: Sequence[int]) -> torch.Tensor:
+        self.hub.objs[self.rank] = list(map(int, send_counts))
+        parts = self._exchange(t.contiguous())
+        counts = [list(c) for c in self.hub.objs]  # type: ignore[arg-type]
+        self.hub.barrier.wait()
+        out = []
+        for src in range(self.world):
+            off = sum(counts[src][: self.rank])
+            out.append(parts[src][off: off + counts[src][self.rank]])
+        return torch.cat(out, dim=0)
+
+    def barrier(self) -> None:
+        self.hub.barrier.wait()
+
+    def max_float(self, x: float) -> float:
+        return float(max(p.item() for p in self._exchange(torch.tensor([x], dtype=torch.float64))))
+
+    def gather_floats(self, xs: Sequence[float]) -> List[float]:
+        self.hub.objs[self.rank] = list(xs)
+        self.hub.barrier.wait()
+        out = [x for part in self.hub.objs for x in part]  # type: ignore[union-attr]
+        self.hub.barrier.wait()
+        return out
+
+    def all_true(self, flag: bool) -> bool:
+        return all(bool(p.item()) for p in self._exchange(torch.tensor([1 if flag else 0])))
+
+
+def run_loopback(world: int, fn) -> list:
+    """Runs ``fn(comm)`` on ``world`` threads sharing a LoopbackHub; returns per-rank results
+    (re-raises the first exception)."""
+    import threading
+
+    hub = LoopbackHub(world)
+    results: List[object] = [None] * world
+    errors: List[Optional[BaseException]] = [None] * world
+
+    def work(r: int) -> None:
+        try:
+            results[r] = fn(LoopbackComm(hub, r))
+        except BaseException as e:  # noqa: BLE001
+            errors[r] = e
+            hub.barrier.abort()
+
+    threads = [threading.Thread(target=work, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    for e in errors:
+        if e is not None and not isinstance(e, threading.BrokenBarrierError):
+            raise e
+    for e in errors:
+        if e is not None:
+            raise e
+    return results
+
+
+def make_comm(dist, device: torch.device, group=None) -> Comm:
+    if dist is None or not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return SingleComm()
+    return TorchDistComm(dist, device, group)
+
+
+def reduce_loopback(parts: List[torch.Tensor]) -> torch.Tensor:
+    """Sum in rank order with one rounding per step, as a ring/tree all-reduce in bf16 would
+    (used by the loopback TP runner so sharded-vs-unsharded comparisons are fair)."""
+    acc = parts[0].float()
+    for p in parts[1:]:
+        acc = acc + p.float()
+    return acc.to(parts[0].dtype)

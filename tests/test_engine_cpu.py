@@ -1,0 +1,146 @@
+"""Engine + model integration on the CPU reference backend: checkpoint round trip,
+logits parity with Hugging Face transformers on the same random weights, greedy decode,
+forked chains, prefix cache, score/embed requests. The same engine code drives the GPU
+kernels (tests/test_engine_gpu.py)."""
+import numpy as np
+import pytest
+import torch
+
+from llm_consensus_amd._native import core
+from llm_consensus_amd.engine.engine import Engine
+from llm_consensus_amd.models.config import from_hf_config, get_preset
+from llm_consensus_amd.models.loader import load_model, write_random_checkpoint
+from llm_consensus_amd.models.transformer import TransformerModel
+
+
+def greedy_params(n_new, seed=0, temperature=0.0):
+    p = core.SamplingParams()
+    p.temperature, p.max_new_tokens, p.ignore_eos, p.seed = temperature, n_new, True, seed
+    return p
+
+
+def hf_model(path):
+    transformers = pytest.importorskip("transformers")
+    m = transformers.AutoModelForCausalLM.from_pretrained(str(path), dtype=torch.float32)
+    m.eval()
+    return m
+
+
+@pytest.fixture(scope="module")
+def ckpts(tmp_path_factory):
+    root = tmp_path_factory.mktemp("ckpt")
+    out = {}
+    for name in ("tiny-llama", "tiny-qwen", "tiny-mistral", "tiny-mixtral"):
+        out[name] = write_random_checkpoint(get_preset(name), root / name, seed=3, std=0.08)
+    return out
+
+
+def test_checkpoint_roundtrip_config(ckpts):
+    for name, path in ckpts.items():
+        cfg = from_hf_config(path)
+        want = get_preset(name)
+        for f in ("vocab_size", "hidden_size", "num_layers", "num_heads", "num_kv_heads", "head_dim",
+                  "intermediate_size", "qkv_bias", "tie_embeddings", "sliding_window", "num_experts",
+                  "experts_per_tok", "model_type"):
+            assert getattr(cfg, f) == getattr(want, f), (name, f)
+
+
+@pytest.mark.parametrize("name", ["tiny-llama", "tiny-qwen", "tiny-mistral", "tiny-mixtral"])
+def test_logits_and_greedy_decode_match_hf(ckpts, name):
+    path = ckpts[name]
+    hf = hf_model(path)
+    model = load_model(str(path), "cpu")
+    eng = Engine(model, num_kv_blocks=64, block_size=16, max_prefill_tokens=40, use_graphs=False)
+    g = torch.Generator().manual_seed(1)
+    prompt = torch.randint(0, model.cfg.vocab_size, (70,), generator=g).tolist()   # > window(48) and > 1 chunk
+    n_new = 12
+    rid = eng.submit(prompt, params=greedy_params(n_new))
+    eng.run_until_done()
+    out = eng.pop_result(rid)
+    with torch.no_grad():
+        ids = torch.tensor([prompt])
+        want = []
+        for _ in range(n_new):
+            logits = hf(ids).logits[0, -1]
+            t = int(logits.argmax())
+            want.append(t)
+            ids = torch.cat([ids, torch.tensor([[t]])], 1)
+    got = out.token_ids[0]
+    # bf16 engine vs fp32 HF: allow a late divergence only if the HF margin there is tiny
+    agree = next((i for i, (a, b) in enumerate(zip(got, want)) if a != b), n_new)
+    assert agree >= 6, (got, want)
+
+
+def test_prefill_logits_close_to_hf(ckpts):
+    path = ckpts["tiny-llama"]
+    hf = hf_model(path)
+    model = load_model(str(path), "cpu")
+    eng = Engine(model, num_kv_blocks=32, block_size=16, use_graphs=False)
+    prompt = list(range(5, 45))
+    tgt = [1, 7, 100, 300]
+    rid = eng.submit(prompt, core.RequestKind.Score, score_ids=tgt)
+    eng.run_until_done()
+    got = np.array(eng.pop_result(rid).scores)
+    with torch.no_grad():
+        lp = torch.log_softmax(hf(torch.tensor([prompt])).logits[0, -1].float(), -1)
+    assert np.allclose(got, lp[tgt].numpy(), atol=0.06)
+
+
+def test_forked_chains_equal_independent_sequences():
+    cfg = get_preset("tiny-llama")
+    model = TransformerModel.random_init(cfg, "cpu", seed=5, std=0.1)
+    prompt = list(range(1, 38))
+    K, n_new = 4, 9
+    eng = Engine(model, num_kv_blocks=128, block_size=16, use_graphs=False)
+    rid = eng.submit(prompt, n=K, params=greedy_params(n_new, seed=100, temperature=0.9))
+    eng.run_until_done()
+    forked = eng.pop_result(rid)
+    st = eng.stats()
+    assert st["kv.cow_copies_total"] >= K - 1
+    eng2 = Engine(model, num_kv_blocks=128, block_size=16, use_graphs=False, enable_prefix_cache=False)
+    rids = [eng2.submit(prompt, params=greedy_params(n_new, seed=100 + k, temperature=0.9)) for k in range(K)]
+    eng2.run_until_done()
+    for k, r in enumerate(rids):
+        assert eng2.pop_result(r).token_ids[0] == forked.token_ids[k], k
+    assert len({tuple(t) for t in forked.token_ids}) > 1      # chains actually differ
+
+
+def test_prefix_cache_gives_identical_results_and_hits():
+    cfg = get_preset("tiny-llama")
+    model = TransformerModel.random_init(cfg, "cpu", seed=6, std=0.1)
+    shared = list(range(3, 3 + 48))
+    a, b = shared + [200, 201, 202], shared + [300, 301]
+    eng = Engine(model, num_kv_blocks=128, block_size=16, use_graphs=False)
+    r1 = eng.submit(a, params=greedy_params(5)); eng.run_until_done(); o1 = eng.pop_result(r1)
+    r2 = eng.submit(b, params=greedy_params(5)); eng.run_until_done(); o2 = eng.pop_result(r2)
+    assert o1.cached_tokens == 0 and o2.cached_tokens == 48
+    cold = Engine(model, num_kv_blocks=128, block_size=16, use_graphs=False, enable_prefix_cache=False)
+    r3 = cold.submit(b, params=greedy_params(5)); cold.run_until_done()
+    assert cold.pop_result(r3).token_ids == o2.token_ids
+    assert eng.stats()["kv.prefix_hit_rate"] > 0.4
+
+
+def test_continuous_batching_mixed_requests_and_decisions():
+    cfg = get_preset("tiny-qwen")
+    model = TransformerModel.random_init(cfg, "cpu", seed=7, std=0.1)
+    eng = Engine(model, num_kv_blocks=256, block_size=16, max_batch_seqs=6, max_prefill_tokens=64, use_graphs=False)
+    rng = np.random.default_rng(0)
+    reqs = {}
+    for i in range(10):
+        prompt = rng.integers(0, cfg.vocab_size, size=int(rng.integers(5, 60))).tolist()
+        n_new = int(rng.integers(1, 8))
+        reqs[eng.submit(prompt, params=greedy_params(n_new), decision_ids=[65, 66, 67, 68])] = (prompt, n_new)
+    emb = eng.submit(list(range(40)), core.RequestKind.Embed)
+    eng.run_until_done()
+    solo = Engine(model, num_kv_blocks=64, block_size=16, use_graphs=False, enable_prefix_cache=False)
+    for rid, (prompt, n_new) in reqs.items():
+        out = eng.pop_result(rid)
+        assert len(out.token_ids[0]) == n_new and len(out.decision_logprobs[0]) == 4
+        r = solo.submit(prompt, params=greedy_params(n_new), decision_ids=[65, 66, 67, 68])
+        solo.run_until_done()
+        ref = solo.pop_result(r)
+        assert ref.token_ids == out.token_ids
+        assert np.allclose(ref.decision_logprobs, out.decision_logprobs, atol=1e-3)
+    e = eng.pop_result(emb).embedding
+    assert e.shape == (cfg.hidden_size,) and abs(np.linalg.norm(e) - 1) < 1e-3
+    assert eng.stats()["kv.blocks_free"] + eng.stats()["kv.blocks_cached"] == 256
