@@ -60,28 +60,46 @@ class _DecodeGraph:
 
     def __init__(self, eng: "Engine", bucket: int, with_prefix: bool) -> None:
         dev = eng.device
-        i32 = dict(dtype=torch.int32, device=dev)
         self.bucket, self.with_prefix = bucket, with_prefix
-        self.token_ids = torch.zeros(bucket, **i32)
-        self.positions = torch.zeros(bucket, **i32)
-        self.slot_mapping = torch.full((bucket,), -1, **i32)
-        self.block_tables = torch.zeros(bucket, eng.max_blocks_cap, **i32)
-        self.ctx_lens = torch.zeros(bucket, **i32)
-        self.temperature = torch.zeros(bucket, dtype=torch.float32, device=dev)
-        self.top_p = torch.ones(bucket, dtype=torch.float32, device=dev)
-        self.top_k = torch.zeros(bucket, **i32)
-        self.seeds = torch.zeros(bucket, dtype=torch.int64, device=dev)
-        self.steps = torch.zeros(bucket, **i32)
-        self.decision_ids = torch.zeros(bucket, eng.max_decision, **i32)
         self.gmax = max(1, bucket // 2)
-        self.group_first = torch.zeros(self.gmax, **i32)
-        self.group_count = torch.zeros(self.gmax, **i32)
-        self.group_shared = torch.zeros(self.gmax, **i32)
-        self.kv_begin = torch.zeros(bucket, **i32)
+        B, MB, C, G = bucket, eng.max_blocks_cap, eng.max_decision, self.gmax
+        # All per-step inputs live in ONE int32 arena: a pinned host mirror is filled with
+        # numpy and shipped with a single H2D copy per step. Field order keeps the int64
+        # seeds 8-byte aligned.
+        fields = [("seeds", 2 * B), ("token_ids", B), ("positions", B), ("slot_mapping", B), ("ctx_lens", B),
+                  ("top_k", B), ("steps", B), ("kv_begin", B), ("temperature", B), ("top_p", B),
+                  ("decision_ids", B * C), ("group_first", G), ("group_count", G), ("group_shared", G),
+                  ("block_tables", B * MB)]
+        total = sum(n for _, n in fields)
+        self.arena = torch.zeros(total, dtype=torch.int32, device=dev)
+        self.host = torch.zeros(total, dtype=torch.int32)
+        if dev.type == "cuda":
+            self.host = self.host.pin_memory()
+        self.h: Dict[str, np.ndarray] = {}
+        off = 0
+        hnp = self.host.numpy()
+        for name, n in fields:
+            d, hv = self.arena[off:off + n], hnp[off:off + n]
+            if name == "seeds":
+                d, hv = d.view(torch.int64), hv.view(np.int64)
+            elif name in ("temperature", "top_p"):
+                d, hv = d.view(torch.float32), hv.view(np.float32)
+            elif name == "decision_ids":
+                d, hv = d.view(B, C), hv.reshape(B, C)
+            elif name == "block_tables":
+                d, hv = d.view(B, MB), hv.reshape(B, MB)
+            setattr(self, name, d)
+            self.h[name] = hv
+            off += n
+        self.h["slot_mapping"][:] = -1
+        self.h["top_p"][:] = 1.0
         self.nsplit = ops.choose_kv_splits(bucket, eng.model.hkv, eng.nominal_ctx)
         self.prefix_splits = max(1, min(8, 1024 // max(1, self.gmax * eng.model.hkv)))
         self.graph: Optional[torch.cuda.CUDAGraph] = None
         self.out_tokens = self.out_lps = self.out_dec = None
+
+    def upload(self) -> None:
+        self.arena.copy_(self.host, non_blocking=True)
 
     def meta(self, eng: "Engine") -> AttnMeta:
         return AttnMeta(
@@ -180,7 +198,8 @@ class Engine:
 
     # ------------------------------------------------------------------ stepping
     def _dev(self, a: np.ndarray, dtype=torch.int32) -> torch.Tensor:
-        return torch.from_numpy(np.ascontiguousarray(a)).to(device=self.device, dtype=dtype, non_blocking=True)
+        # Blocking copy: the source is a temporary pageable buffer that dies with this call.
+        return torch.from_numpy(np.ascontiguousarray(a)).to(device=self.device, dtype=dtype)
 
     def step(self) -> bool:
         plan = self.sched.schedule()
@@ -270,23 +289,25 @@ class Engine:
             if not self.use_graphs:
                 g.nsplit = 1 if self.device.type != "cuda" else g.nsplit
             self._graphs[key] = g
-        # ---- fill static inputs ----
-        def put(dst: torch.Tensor, a: np.ndarray, fill=0):
-            n = a.shape[0]
-            dst[:n].copy_(torch.from_numpy(np.ascontiguousarray(a)).to(dst.dtype), non_blocking=True)
-            if n < dst.shape[0]:
-                dst[n:].fill_(fill)
+        # ---- fill the pinned host mirror, then one H2D copy ----
+        h = g.h
 
-        put(g.token_ids, plan.token_ids)
-        put(g.positions, plan.positions)
-        put(g.slot_mapping, plan.slot_mapping, -1)
-        put(g.ctx_lens, plan.context_lens)
+        def put(name: str, a: np.ndarray, fill=0):
+            dst = h[name]
+            n = a.shape[0]
+            dst[:n] = a
+            if n < dst.shape[0]:
+                dst[n:] = fill
+
+        put("token_ids", plan.token_ids)
+        put("positions", plan.positions)
+        put("slot_mapping", plan.slot_mapping, -1)
+        put("ctx_lens", plan.context_lens)
         bt = plan.block_tables
-        g.block_tables[:B, : bt.shape[1]].copy_(torch.from_numpy(np.maximum(bt, 0)), non_blocking=True)
+        h["block_tables"][:B, : bt.shape[1]] = np.maximum(bt, 0)
         req_ids = plan.request_ids
-        temp = np.zeros(B, np.float32); top_p = np.ones(B, np.float32); top_k = np.zeros(B, np.int32)
-        dec = np.zeros((B, self.max_decision), np.int32)
         cache: Dict[int, tuple] = {}
+        any_decision = False
         for b in range(B):
             rid = int(req_ids[b])
             e = cache.get(rid)
@@ -295,28 +316,30 @@ class Engine:
                 d = self._reqs[rid].decision_ids
                 e = (p.temperature, p.top_p, p.top_k, d)
                 cache[rid] = e
-            temp[b], top_p[b], top_k[b] = e[0], e[1], e[2]
+            h["temperature"][b], h["top_p"][b], h["top_k"][b] = e[0], e[1], e[2]
             if e[3]:
-                dec[b, : len(e[3])] = e[3]
-        put(g.temperature, temp)
-        put(g.top_p, top_p, 1)
-        put(g.top_k, top_k)
-        put(g.seeds, plan.seeds.astype(np.int64))
-        put(g.steps, plan.step_index)
-        g.decision_ids[:B].copy_(torch.from_numpy(dec), non_blocking=True)
+                any_decision = True
+                h["decision_ids"][b, : len(e[3])] = e[3]
+        if B < bucket:
+            h["temperature"][B:] = 0.0
+            h["top_p"][B:] = 1.0
+            h["top_k"][B:] = 0
+        put("seeds", plan.seeds.astype(np.int64))
+        put("steps", plan.step_index)
         if with_prefix:
             ng = len(gcount)
             if ng > g.gmax:
                 raise RuntimeError("more sequence groups than the decode graph was sized for")
-            put(g.group_first, plan.group_first)
-            put(g.group_count, np.where(gshared > 0, gcount, 0).astype(np.int32))
-            put(g.group_shared, gshared)
+            put("group_first", plan.group_first)
+            put("group_count", np.where(gshared > 0, gcount, 0).astype(np.int32))
+            put("group_shared", gshared)
             kvb = np.zeros(B, np.int32)
             for gi in range(ng):
                 if gshared[gi] > 0 and gcount[gi] > 1:
                     f, c = int(plan.group_first[gi]), int(gcount[gi])
                     kvb[f:f + c] = int(gshared[gi]) * self.block_size
-            put(g.kv_begin, kvb)
+            put("kv_begin", kvb)
+        g.upload()
         # ---- run ----
         if self.use_graphs:
             if g.graph is None:
@@ -327,7 +350,7 @@ class Engine:
             tok, lp, dl = g.run_body(self)
         tok_h = tok[:B].cpu().numpy()
         lp_h = lp[:B].cpu().numpy()
-        if any(e[3] for e in cache.values()):
+        if any_decision:
             dl_h = dl[:B].cpu().numpy()
             for b in range(B):
                 st = self._reqs[int(req_ids[b])]

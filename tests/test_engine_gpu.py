@@ -51,25 +51,40 @@ def copy_weights(src: TransformerModel, dst: TransformerModel):
 
 @pytest.mark.parametrize("name", ["tiny-llama", "tiny-qwen", "tiny-mistral", "tiny-mixtral", "small-llama"])
 def test_gpu_engine_matches_cpu_engine(name):
+    """Random-weight models have near-flat next-token distributions, so arg-max sequences may
+    legitimately fork on a bf16 rounding difference. Parity is therefore checked on log-probs
+    with teacher forcing: both engines score the CPU engine's own continuation."""
     cpu, gpu = models(name)
     copy_weights(cpu, gpu)
     rng = np.random.default_rng(0)
     prompts = [rng.integers(0, cpu.cfg.vocab_size, size=n).tolist() for n in (5, 70, 33, 64, 129)]
-    outs = []
-    for m, graphs in ((cpu, False), (gpu, False), (gpu, True)):
-        eng = Engine(m, num_kv_blocks=128, block_size=16, max_prefill_tokens=96, use_graphs=graphs)
-        rids = [eng.submit(p, params=params(10), decision_ids=[1, 2, 3]) for p in prompts]
-        sc = eng.submit(prompts[1], core.RequestKind.Score, score_ids=[4, 5, 6, 7])
+    n_new = 10
+
+    def generate(m, graphs):
+        eng = Engine(m, num_kv_blocks=256, block_size=16, max_prefill_tokens=96, use_graphs=graphs)
+        rids = [eng.submit(p, params=params(n_new), decision_ids=[1, 2, 3]) for p in prompts]
         eng.run_until_done()
-        outs.append(([eng.pop_result(r) for r in rids], eng.pop_result(sc)))
-    (c_gen, c_sc), (g_gen, g_sc), (gg_gen, gg_sc) = outs
-    assert np.allclose(c_sc.scores, g_sc.scores, atol=0.08)
-    assert np.allclose(g_sc.scores, gg_sc.scores, atol=1e-5)
-    for a, b, c in zip(c_gen, g_gen, gg_gen):
-        agree = next((i for i, (x, y) in enumerate(zip(a.token_ids[0], b.token_ids[0])) if x != y), 10)
-        assert agree >= 4, (a.token_ids, b.token_ids)     # bf16 kernels vs fp32-math oracle: late argmax flips only
+        return [eng.pop_result(r) for r in rids]
+
+    c_gen, g_gen, gg_gen = generate(cpu, False), generate(gpu, False), generate(gpu, True)
+    for b, c in zip(g_gen, gg_gen):
         assert b.token_ids == c.token_ids                   # graph replay == eager, bit for bit
         assert np.allclose(b.decision_logprobs, c.decision_logprobs, atol=1e-5)
+    first_same = sum(a.token_ids[0][0] == b.token_ids[0][0] for a, b in zip(c_gen, g_gen))
+    assert first_same >= 3
+
+    def score(m):
+        eng = Engine(m, num_kv_blocks=256, block_size=16, max_prefill_tokens=96, use_graphs=False)
+        rids = []
+        for p, out in zip(prompts, c_gen):
+            toks = out.token_ids[0]
+            for k in (0, 4, 9):
+                rids.append(eng.submit(p + toks[:k], core.RequestKind.Score, score_ids=[toks[k], 7, 100, 300]))
+        eng.run_until_done()
+        return np.array([eng.pop_result(r).scores for r in rids])
+
+    sc_c, sc_g = score(cpu), score(gpu)
+    assert np.abs(sc_c - sc_g).max() < 0.08, np.abs(sc_c - sc_g).max()
 
 
 @pytest.mark.parametrize("name,bs", [("small-llama", 64), ("tiny-qwen", 16)])
@@ -77,20 +92,37 @@ def test_forked_chains_use_shared_prefix_and_match_independent(name, bs):
     _, gpu = models(name, seed=2, std=0.1)
     prompt = list(range(1, 1 + 3 * bs + 7))
     K, n_new = 16, 12
-    eng = Engine(gpu, num_kv_blocks=256, block_size=bs, use_graphs=True)
-    rid = eng.submit(prompt, n=K, params=params(n_new, seed=500, temperature=0.8, top_p=0.95))
-    eng.run_until_done()
-    forked = eng.pop_result(rid)
+
+    def forked(temp, graphs, group_rows):
+        eng = Engine(gpu, num_kv_blocks=512, block_size=bs, use_graphs=graphs, max_group_rows=group_rows)
+        rid = eng.submit(prompt, n=K, params=params(n_new, seed=500, temperature=temp, top_p=0.95))
+        eng.run_until_done()
+        return eng.pop_result(rid), eng
+
+    def independent(temp):
+        eng = Engine(gpu, num_kv_blocks=512, block_size=bs, use_graphs=False, enable_prefix_cache=False)
+        rids = [eng.submit(prompt, params=params(n_new, seed=500 + k, temperature=temp, top_p=0.95)) for k in range(K)]
+        eng.run_until_done()
+        return [eng.pop_result(r) for r in rids]
+
+    # 1) fork / copy-on-write / per-chain RNG streams: without the prefix pass the forked chains are
+    #    bit-identical to K independent sequences with seeds seed+k, even when sampling.
+    ind = independent(0.8)
+    f_plain, eng = forked(0.8, False, 0)
+    assert not any(k[1] for k in eng._graphs)
+    assert [r.token_ids[0] for r in ind] == f_plain.token_ids
+    assert len({tuple(t) for t in f_plain.token_ids}) > K // 2
+    assert eng.stats()["kv.cow_copies_total"] >= K - 1
+    # 2) shared-prefix attention (prefix pass + suffix pass + merge): same arg-max tokens as the
+    #    one-pass kernel, and sampled chains stay equally likely (rounding moves a flat CDF).
+    ind0 = independent(0.0)
+    f0, eng = forked(0.0, True, 16)
     assert any(k[1] for k in eng._graphs), "shared-prefix decode graph was never used"
-    ind = Engine(gpu, num_kv_blocks=512, block_size=bs, use_graphs=False, enable_prefix_cache=False)
-    rids = [ind.submit(prompt, params=params(n_new, seed=500 + k, temperature=0.8, top_p=0.95)) for k in range(K)]
-    ind.run_until_done()
-    same = 0
-    for k, r in enumerate(rids):
-        same += ind.pop_result(r).token_ids[0] == forked.token_ids[k]
-    # prefix+suffix+merge vs one-pass attention differ in rounding; sampled chains may diverge rarely
-    assert same >= K - 3
-    assert len({tuple(t) for t in forked.token_ids}) > K // 2
+    assert sum(a.token_ids[0] == b for a, b in zip(ind0, f0.token_ids)) >= K - 2
+    f_pref, _ = forked(0.8, True, 16)
+    mean_ind = np.mean([r.cum_logprobs[0] for r in ind])
+    assert abs(np.mean(f_pref.cum_logprobs) - mean_ind) < 0.15 * abs(mean_ind)
+    assert sum(a.token_ids[0] == b for a, b in zip(ind, f_pref.token_ids)) >= 2
 
 
 def test_strategies_end_to_end_on_gpu_backend():
