@@ -13,10 +13,25 @@ from llm_consensus_amd import ops  # noqa: E402
 DEV = "cuda"
 
 
-def timeit(fn, iters=20, warmup=3):
+def timeit(fn, iters=20, warmup=3, graph=True):
+    """Time per call in us. With graph=True the calls are captured into one hipGraph so host
+    launch overhead (ctypes + allocator, ~15 us per op) does not mask short kernels."""
     for _ in range(warmup):
         fn()
     torch.cuda.synchronize()
+    if graph:
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            for _ in range(iters):
+                fn()
+        g.replay()
+        torch.cuda.synchronize()
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        g.replay()
+        e.record()
+        torch.cuda.synchronize()
+        return s.elapsed_time(e) / iters * 1e3
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     s.record()
     for _ in range(iters):
@@ -48,7 +63,7 @@ def bench_gemm(results):
                 row[name + "_us"] = round(us, 2)
                 row[name + "_tflops"] = round(2 * M * N * K / us / 1e6, 1)
                 row[name + "_gbs"] = round((N * K * 2 + M * K * 2 + M * N * 2) / us / 1e3, 1)
-            ops.WS_MAX_M = 128
+            ops.WS_MAX_M = 256
             us = timeit(lambda: X @ W.t())
             row["torch_us"] = round(us, 2)
             row["torch_tflops"] = round(2 * M * N * K / us / 1e6, 1)

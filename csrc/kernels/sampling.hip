@@ -3,20 +3,25 @@
 //   lc_sample         temperature -> top-k -> top-p -> categorical draw; returns the token
 //                     and its log-probability under the distribution it was drawn from.
 //                     temperature == 0 selects the arg-max (log-prob under softmax(logits)).
-//                     Top-k / top-p use threshold bisection (count / mass above a value)
-//                     instead of sorting the vocabulary: a pass is one coalesced sweep.
+//                     Top-k / top-p never sort the vocabulary: the kept set is {z >= thr}
+//                     and thr is found by a 12-way threshold search (per-thread LDS
+//                     histograms), each sweep one coalesced 16-byte-per-lane pass over the row.
 //   lc_logprob_gather log-softmax over the vocabulary, gathered at given target ids: the
 //                     constrained decision used for verdicts ("Good" vs "NeedsRefinement",
 //                     the two words the reference's parser accepts,
 //                     /root/reference/src/main.rs:144-148) and multiple-choice answers.
 //
 // One 1024-thread block per row. Randomness is counter-based (seed, step) so a chain's
-// tokens do not depend on which other sequences share its batch.
+// tokens do not depend on which other sequences share its batch. The inverse-CDF draw
+// walks the vocabulary in index order (wave-contiguous segments + wave prefix scans).
 #include "common.h"
 
 namespace {
 
 constexpr int kThreads = 1024;
+constexpr int kWaves = kThreads / 64;
+constexpr int kBins = 12;          // threshold-search fan-out per sweep (12 x 1024 floats of LDS)
+constexpr int kSearchPasses = 6;   // 30 / 12^6 ~ 1e-5 resolution in logit/T units
 
 struct ArgMax {
   float v;
@@ -28,37 +33,21 @@ LC_DEVICE ArgMax argmax_combine(ArgMax a, ArgMax b) {
   return a;
 }
 
-LC_DEVICE ArgMax block_argmax(ArgMax x, float* sv, int* si) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) {
-    ArgMax o{__shfl_xor(x.v, off, 64), __shfl_xor(x.i, off, 64)};
-    x = argmax_combine(x, o);
-  }
-  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
-  __syncthreads();
-  if (lane == 0) {
-    sv[wid] = x.v;
-    si[wid] = x.i;
-  }
-  __syncthreads();
-  ArgMax r{sv[0], si[0]};
-  for (int i = 1; i < nw; ++i) r = argmax_combine(r, ArgMax{sv[i], si[i]});
-  return r;
-}
-
-// mass and count of entries with z >= thr, where z = logit * inv_t and weights exp(z - zmax)
-LC_DEVICE void mass_above(const float* __restrict__ row, int V, float inv_t, float zmax, float thr,
-                          float* red, float* mass, float* count) {
-  float m = 0.f, c = 0.f;
-  for (int i = threadIdx.x; i < V; i += blockDim.x) {
-    const float z = row[i] * inv_t;
-    if (z >= thr) {
-      m += __expf(z - zmax);
-      c += 1.f;
+// Visits every element of the row once as (value, index); 16-byte loads when the row is
+// 16-byte aligned and V % 4 == 0, scalar loads otherwise.
+template <typename F>
+LC_DEVICE void for_each_strided(const float* __restrict__ row, int V, bool vec, F&& f) {
+  if (vec) {
+    for (int i = threadIdx.x * 4; i < V; i += kThreads * 4) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(row + i);
+      f(v[0], i);
+      f(v[1], i + 1);
+      f(v[2], i + 2);
+      f(v[3], i + 3);
     }
+  } else {
+    for (int i = threadIdx.x; i < V; i += kThreads) f(row[i], i);
   }
-  *mass = block_sum(m, red);
-  *count = block_sum(c, red);
 }
 
 __global__ __launch_bounds__(kThreads) void sample_kernel(
@@ -67,153 +56,201 @@ __global__ __launch_bounds__(kThreads) void sample_kernel(
     const uint64_t* __restrict__ seeds, const int32_t* __restrict__ steps, int32_t* __restrict__ out_token,
     float* __restrict__ out_logprob) {
   __shared__ float red[16];
-  __shared__ float sv[16];
-  __shared__ int si[16];
-  __shared__ float partial[kThreads];
-  __shared__ int chosen;
+  __shared__ float sv[kWaves];
+  __shared__ int si[kWaves];
+  __shared__ float multi[kWaves][kBins];
+  extern __shared__ float hist[];  // [kBins][kThreads]
+  __shared__ float seg_sum[kWaves];
+  __shared__ float bc[2];
+  __shared__ int bci[1];
   const int r = blockIdx.x;
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const float* row = logits + static_cast<size_t>(row_index ? row_index[r] : r) * ld;
+  const bool vec = (V % 4 == 0) && ((reinterpret_cast<uintptr_t>(row) & 15) == 0);
   const float T = temperature[r];
   const bool greedy = !(T > 0.f);
   const float inv_t = greedy ? 1.f : 1.f / T;
 
-  // pass 1: arg-max of z
+  // ---- pass 1: arg-max of z = logit / T ----
   ArgMax am{-INFINITY, 0x7fffffff};
-  for (int i = threadIdx.x; i < V; i += blockDim.x) am = argmax_combine(am, ArgMax{row[i] * inv_t, i});
-  am = block_argmax(am, sv, si);
+  for_each_strided(row, V, vec, [&](float x, int i) { am = argmax_combine(am, ArgMax{x * inv_t, i}); });
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1)
+    am = argmax_combine(am, ArgMax{__shfl_xor(am.v, off, 64), __shfl_xor(am.i, off, 64)});
+  if (lane == 0) {
+    sv[wid] = am.v;
+    si[wid] = am.i;
+  }
+  __syncthreads();
+  am = ArgMax{sv[0], si[0]};
+  for (int i = 1; i < kWaves; ++i) am = argmax_combine(am, ArgMax{sv[i], si[i]});
   const float zmax = am.v;
-  // pass 2: partition function
-  float total, cnt_all;
-  mass_above(row, V, inv_t, zmax, -INFINITY, red, &total, &cnt_all);
+
+  // ---- pass 2: partition function (relative to zmax) ----
+  float tsum = 0.f;
+  for_each_strided(row, V, vec, [&](float x, int) { tsum += __expf(x * inv_t - zmax); });
+  const float total = block_sum(tsum, red);
   if (greedy) {
     if (threadIdx.x == 0) {
       out_token[r] = am.i;
-      out_logprob[r] = -__logf(total);  // z_max - zmax - log(sum)
+      out_logprob[r] = -__logf(total);
     }
     return;
   }
 
-  float thr = -INFINITY;  // kept set = { z >= thr }
+  // ---- threshold search: kept set = { z >= thr } ----
+  float thr = -INFINITY;
   float kept_mass = total;
   const int k = top_k ? top_k[r] : 0;
-  if (k > 0 && k < V) {
-    // largest threshold that still keeps >= k entries
-    float lo = zmax - 60.f, hi = zmax;  // count(lo) >= k assumed (entries 60 nats below max carry no mass)
-    float m_lo, c_lo;
-    mass_above(row, V, inv_t, zmax, lo, red, &m_lo, &c_lo);
-    if (c_lo >= static_cast<float>(k)) {
-      for (int it = 0; it < 30; ++it) {
-        const float mid = 0.5f * (lo + hi);
-        float m, c;
-        mass_above(row, V, inv_t, zmax, mid, red, &m, &c);
-        if (c >= static_cast<float>(k)) {
-          lo = mid;
-          m_lo = m;
-          if (c == static_cast<float>(k)) break;
-        } else {
-          hi = mid;
+  const float p = top_p ? top_p[r] : 1.f;
+  const bool use_k = k > 0 && k < V, use_p = p < 1.f;
+  for (int phase = 0; phase < 2; ++phase) {
+    if (phase == 0 ? !use_k : !use_p) continue;
+    // Entries more than 30 below the max carry < 1e-13 of the mass each: start there.
+    float lo = fmaxf(thr, zmax - 30.f), hi = zmax;
+    const float target = phase == 0 ? static_cast<float>(k) : p * kept_mass;
+    bool found = false;
+    for (int it = 0; it < kSearchPasses; ++it) {
+      // Per-thread histogram over kBins equal sub-intervals of [lo, hi): thread t owns column t
+      // of hist[kBins][kThreads] (conflict-free, no atomics). Entries >= hi land in the top bin,
+      // so suffix sums give the mass (or count) above each threshold t_j = lo + w*j.
+      const float w = (hi - lo) * (1.f / kBins);
+      const float inv_w = w > 0.f ? 1.f / w : 0.f;
+#pragma unroll
+      for (int j = 0; j < kBins; ++j) hist[j * kThreads + threadIdx.x] = 0.f;
+      for_each_strided(row, V, vec, [&](float x, int) {
+        const float z = x * inv_t;
+        if (z >= lo) {
+          int b = static_cast<int>((z - lo) * inv_w);
+          b = b < kBins - 1 ? b : kBins - 1;
+          hist[b * kThreads + threadIdx.x] += phase == 0 ? 1.f : __expf(z - zmax);
+        }
+      });
+      float bins[kBins];
+#pragma unroll
+      for (int j = 0; j < kBins; ++j) bins[j] = wave_sum(hist[j * kThreads + threadIdx.x]);
+      __syncthreads();
+      if (lane == 0) {
+#pragma unroll
+        for (int j = 0; j < kBins; ++j) multi[wid][j] = bins[j];
+      }
+      __syncthreads();
+      // every thread walks the thresholds from the top; the result is block-uniform
+      int best = -1;
+      float cum = 0.f, best_v = 0.f;
+      for (int j = kBins - 1; j >= 0 && best < 0; --j) {
+        for (int wv = 0; wv < kWaves; ++wv) cum += multi[wv][j];
+        if (cum >= target) {
+          best = j;
+          best_v = cum;
         }
       }
+      if (best < 0) break;  // even {z >= lo} misses the target: keep the previous edge
+      const float nlo = lo + w * static_cast<float>(best);
+      const float nhi = best >= kBins - 1 ? hi : lo + w * static_cast<float>(best + 1);
+      lo = nlo;
+      hi = nhi;
       thr = lo;
-      kept_mass = m_lo;
+      found = true;
+      if (phase == 0 && best_v == target) break;
     }
-  }
-  const float p = top_p ? top_p[r] : 1.f;
-  if (p < 1.f) {
-    // largest threshold whose kept mass is still >= p * (mass after top-k)
-    const float target = p * kept_mass;
-    float lo = fmaxf(thr, zmax - 60.f), hi = zmax;
-    float m_lo, c_lo;
-    mass_above(row, V, inv_t, zmax, lo, red, &m_lo, &c_lo);
-    for (int it = 0; it < 30; ++it) {
-      const float mid = 0.5f * (lo + hi);
-      float m, c;
-      mass_above(row, V, inv_t, zmax, mid, red, &m, &c);
-      if (m >= target) {
-        lo = mid;
-        m_lo = m;
-        c_lo = c;
-      } else {
-        hi = mid;
-      }
+    if (found && phase == 0 && use_p) {
+      // top-p is relative to the mass that survived top-k
+      float m = 0.f;
+      for_each_strided(row, V, vec, [&](float x, int) {
+        const float z = x * inv_t;
+        m += z >= thr ? __expf(z - zmax) : 0.f;
+      });
+      kept_mass = block_sum(m, red);
     }
-    thr = lo;
-    kept_mass = m_lo;
   }
 
-  // draw: u * kept_mass located by an index-ordered scan (contiguous chunk per thread)
+  // ---- draw: locate u * kept_mass in the index-ordered CDF of the kept set ----
   const float u = rng_uniform(seeds[r], static_cast<uint32_t>(steps ? steps[r] : 0), 0);
-  const int chunk = (V + blockDim.x - 1) / blockDim.x;
-  const int b0 = threadIdx.x * chunk, b1 = min(V, b0 + chunk);
-  float mine = 0.f;
-  for (int i = b0; i < b1; ++i) {
+  const int seg = ((V + kWaves - 1) / kWaves + 255) & ~255;  // elements per wave, multiple of 256
+  const int s0 = wid * seg, s1 = min(V, s0 + seg);
+  auto kept_w = [&](int i) -> float {
+    if (i >= s1) return 0.f;
     const float z = row[i] * inv_t;
-    if (z >= thr) mine += __expf(z - zmax);
-  }
-  partial[threadIdx.x] = mine;
-  if (threadIdx.x == 0) chosen = -1;
+    return z >= thr ? __expf(z - zmax) : 0.f;
+  };
+  float mine = 0.f;
+  for (int i = s0 + lane * 4; i < s1; i += 256) mine += kept_w(i) + kept_w(i + 1) + kept_w(i + 2) + kept_w(i + 3);
+  mine = wave_sum(mine);
+  if (lane == 0) seg_sum[wid] = mine;
   __syncthreads();
-  if (threadIdx.x < 64) {
-    // wave 0 scans the 1024 partials: 16 per lane
-    float acc = 0.f;
-    for (int j = 0; j < 16; ++j) acc += partial[threadIdx.x * 16 + j];
-    float incl = acc;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-      const float o = __shfl_up(incl, off, 64);
-      if (static_cast<int>(threadIdx.x) >= off) incl += o;
-    }
-    const float grand = __shfl(incl, 63, 64);
+  if (threadIdx.x == 0) {
+    float grand = 0.f;
+    for (int w2 = 0; w2 < kWaves; ++w2) grand += seg_sum[w2];
     const float target = u * grand;
-    float before = incl - acc;
-    // the lane whose span contains the target
-    const bool here = (target >= before) && (target < incl || threadIdx.x == 63);
-    const unsigned long long ball = __ballot(here);
-    const int owner = ball ? __ffsll(static_cast<long long>(ball)) - 1 : 63;
-    if (static_cast<int>(threadIdx.x) == owner) {
-      float run = before;
-      int pick = threadIdx.x * 16 + 15;
-      for (int j = 0; j < 16; ++j) {
-        const float nxt = run + partial[threadIdx.x * 16 + j];
-        if (target < nxt) {
-          pick = threadIdx.x * 16 + j;
-          break;
-        }
-        run = nxt;
+    float run = 0.f;
+    int owner = 0;
+    for (int w2 = 0; w2 < kWaves; ++w2) {
+      if (seg_sum[w2] > 0.f) {
+        owner = w2;  // last non-empty segment so far: fallback when target == grand
+        if (target < run + seg_sum[w2]) break;
       }
-      // skip empty trailing chunks (when the target equals the grand total)
-      while (pick > 0 && partial[pick] == 0.f) --pick;
-      chosen = pick;
-      float base = 0.f;
-      for (int j = 0; j < pick; ++j) base += partial[j];
-      partial[0] = fmaxf(target - base, 0.f);  // residual inside the chosen chunk
-      partial[1] = grand;
+      run += seg_sum[w2];
     }
+    run = 0.f;
+    for (int w2 = 0; w2 < owner; ++w2) run += seg_sum[w2];
+    bc[0] = fmaxf(target - run, 0.f);
+    bc[1] = grand;
+    bci[0] = owner;
   }
   __syncthreads();
-  if (static_cast<int>(threadIdx.x) == chosen) {
-    const float resid = partial[0], grand = partial[1];
+  if (wid == bci[0]) {
+    const float resid = bc[0], grand = bc[1];
     float run = 0.f;
     int tok = -1, last_kept = -1;
-    float ztok = 0.f;
-    for (int i = b0; i < b1; ++i) {
-      const float z = row[i] * inv_t;
-      if (z >= thr) {
-        last_kept = i;
-        run += __expf(z - zmax);
-        if (resid < run) {
-          tok = i;
-          ztok = z;
-          break;
-        }
+    for (int base = s0; base < s1 && tok < 0; base += 256) {
+      const int i = base + lane * 4;
+      const float w0 = kept_w(i), w1 = kept_w(i + 1), w2 = kept_w(i + 2), w3 = kept_w(i + 3);
+      const float mysum = w0 + w1 + w2 + w3;
+      float incl = mysum;
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) {
+        const float o = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += o;
       }
+      const float before = run + incl - mysum;
+      const bool hit = mysum > 0.f && resid < run + incl;
+      const unsigned long long hm = __ballot(hit);
+      const unsigned long long km = __ballot(mysum > 0.f);
+      if (km) {
+        // last kept element seen so far (fallback when rounding never crosses resid)
+        const int hl = 63 - __clzll(static_cast<long long>(km));
+        int lk = -1;
+        if (lane == hl) {
+          const float ws[4] = {w0, w1, w2, w3};
+          for (int q = 0; q < 4; ++q)
+            if (ws[q] > 0.f) lk = i + q;
+        }
+        last_kept = __shfl(lk, hl, 64);
+      }
+      if (hm) {
+        const int first = __ffsll(static_cast<long long>(hm)) - 1;
+        int mytok = -1;
+        if (lane == first) {
+          float c = before;
+          const float ws[4] = {w0, w1, w2, w3};
+          for (int q = 0; q < 4; ++q) {
+            if (ws[q] > 0.f) {
+              mytok = i + q;
+              c += ws[q];
+              if (resid < c) break;
+            }
+          }
+        }
+        tok = __shfl(mytok, first, 64);
+      }
+      run += __shfl(incl, 63, 64);
     }
-    if (tok < 0) {
-      tok = last_kept >= 0 ? last_kept : am.i;
-      ztok = row[tok] * inv_t;
+    if (tok < 0) tok = last_kept >= 0 ? last_kept : am.i;
+    if (lane == 0) {
+      out_token[r] = tok;
+      out_logprob[r] = (row[tok] * inv_t - zmax) - __logf(grand);
     }
-    out_token[r] = tok;
-    out_logprob[r] = (ztok - zmax) - __logf(grand);
   }
 }
 
@@ -224,13 +261,20 @@ __global__ __launch_bounds__(kThreads) void logprob_gather_kernel(
   __shared__ float red[16];
   const int r = blockIdx.x;
   const float* row = logits + static_cast<size_t>(row_index ? row_index[r] : r) * ld;
-  float mx = -INFINITY;
-  for (int i = threadIdx.x; i < V; i += blockDim.x) mx = fmaxf(mx, row[i]);
-  mx = block_max(mx, red);
-  float s = 0.f;
-  for (int i = threadIdx.x; i < V; i += blockDim.x) s += __expf(row[i] - mx);
-  s = block_sum(s, red);
-  const float logz = mx + __logf(s);
+  const bool vec = (V % 4 == 0) && ((reinterpret_cast<uintptr_t>(row) & 15) == 0);
+  // online max + rescaled sum in one pass
+  float mx = -INFINITY, s = 0.f;
+  for_each_strided(row, V, vec, [&](float x, int) {
+    if (x > mx) {
+      s = s * __expf(mx - x) + 1.f;
+      mx = x;
+    } else {
+      s += __expf(x - mx);
+    }
+  });
+  const float bmx = block_max(mx, red);
+  s = block_sum(mx == -INFINITY ? 0.f : s * __expf(mx - bmx), red);
+  const float logz = bmx + __logf(s);
   for (int c = threadIdx.x; c < C; c += blockDim.x) {
     int id = ids[static_cast<size_t>(r) * id_stride + c];
     id = id < 0 ? 0 : (id >= V ? V - 1 : id);
@@ -244,7 +288,7 @@ LC_EXPORT int lc_sample(const void* logits, int V, int ld, const void* row_index
                         const void* top_p, const void* top_k, const void* seeds, const void* steps,
                         void* out_token, void* out_logprob, int R, hipStream_t stream) {
   if (R <= 0) return 0;
-  sample_kernel<<<dim3(R), dim3(kThreads), 0, stream>>>(
+  sample_kernel<<<dim3(R), dim3(kThreads), kBins * kThreads * sizeof(float), stream>>>(
       static_cast<const float*>(logits), V, ld, static_cast<const int32_t*>(row_index),
       static_cast<const float*>(temperature), static_cast<const float*>(top_p),
       static_cast<const int32_t*>(top_k), static_cast<const uint64_t*>(seeds),

@@ -18,7 +18,7 @@ from . import reference as ref
 EPI_BF16, EPI_F32, EPI_SWIGLU = 0, 1, 2
 
 # M at or below which the weight-streaming kernel is used instead of the 128x128 tile kernel.
-WS_MAX_M = int(os.environ.get("LC_WS_MAX_M", "128"))
+WS_MAX_M = int(os.environ.get("LC_WS_MAX_M", "256"))
 # Target number of workgroups for the weight-streaming kernel (256 CUs on MI355X).
 WS_TARGET_BLOCKS = int(os.environ.get("LC_WS_TARGET_BLOCKS", "256"))
 

@@ -47,12 +47,13 @@ def test_gemm_tile(M, N, K, bias):
     W = bf(rand(N, K, scale=0.5, seed=1) + torch.arange(N)[:, None] * 1e-3)
     b = bf(rand(N, seed=2)) if bias else None
     lw = ops.LinearWeight.from_dense(W, b, DEV)
+    old = ops.WS_MAX_M
     ops.WS_MAX_M = 0
     try:
         y = ops.linear(X.to(DEV), lw)
         y32 = ops.linear(X.to(DEV), lw, out_f32=True)
     finally:
-        ops.WS_MAX_M = 128
+        ops.WS_MAX_M = old
     want = ref.linear(X, W, b, torch.float32)
     assert rel_err(y, want) < 6e-3
     assert rel_err(y32, want) < 1e-4
