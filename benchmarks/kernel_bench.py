@@ -41,20 +41,25 @@ def timeit(fn, iters=20, warmup=3, graph=True):
     return s.elapsed_time(e) / iters * 1e3  # us
 
 
+MS = tuple(int(x) for x in os.environ.get("LC_BENCH_MS", "1,16,64,128,256,1024,8192").split(","))
+
+
 def bench_gemm(results):
     shapes = [(4096, 4096), (6144, 4096), (28672, 4096), (4096, 14336), (128256, 4096)]
     for N, K in shapes:
         W = (torch.randn(N, K, device=DEV) * 0.05).bfloat16()
         lw = ops.LinearWeight.from_dense(W, None, DEV)
-        for M in (1, 16, 64, 128, 256, 1024, 8192):
+        for M in MS:
             if N > 100000 and M > 256:
                 continue
             X = (torch.randn(M, K, device=DEV) * 0.5).bfloat16()
             row = {"op": "linear", "M": M, "N": N, "K": K}
-            for name, ws_max in (("ws", 256), ("tile", 0)):
+            for name, ws_max, g256 in (("ws", 256, -1), ("tile", 0, -1), ("g256", 0, 0)):
                 if name == "ws" and M > 256:
                     continue
-                ops.WS_MAX_M = ws_max
+                if name == "g256" and (M < 256 or lw.n_pad % 256):
+                    continue
+                ops.WS_MAX_M, ops.GEMM256_MIN_TILES = ws_max, g256
                 try:
                     us = timeit(lambda: ops.linear(X, lw))
                 except Exception as ex:  # noqa: BLE001
@@ -63,7 +68,7 @@ def bench_gemm(results):
                 row[name + "_us"] = round(us, 2)
                 row[name + "_tflops"] = round(2 * M * N * K / us / 1e6, 1)
                 row[name + "_gbs"] = round((N * K * 2 + M * K * 2 + M * N * 2) / us / 1e3, 1)
-            ops.WS_MAX_M = 256
+            ops.WS_MAX_M, ops.GEMM256_MIN_TILES = 256, 192
             us = timeit(lambda: X @ W.t())
             row["torch_us"] = round(us, 2)
             row["torch_tflops"] = round(2 * M * N * K / us / 1e6, 1)

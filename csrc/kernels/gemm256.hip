@@ -1,0 +1,220 @@
+// Large-M bf16 GEMM, 256(n) x 256(m) x 64(k) block tile, 8 waves, LDS-DMA staging that
+// stays in flight across barriers (counted s_waitcnt vmcnt, raw s_barrier).
+//
+// Same operand conventions as gemm.hip: packed weights (MFMA-fragment order) are the
+// MFMA A operand, activations the B operand, both staged with global_load_lds_dwordx4
+// into a lane-linear LDS image (conflict-free ds_read_b128).
+//
+// Work split. Wave (wn = w&3, wm = w>>2) owns 64 n x 128 m of the tile = 4 x 8
+// accumulator fragments (128 VGPRs). A K-tile (64 deep) is consumed in four phases of
+// 16 MFMAs, one 2(nt) x 4(mt) quadrant each, in the order
+//     P1 (n-lo, m-lo)   P2 (n-hi, m-lo)   P3 (n-hi, m-hi)   P4 (n-lo, m-hi)
+// so all 8 weight fragments are read once in P1 and the activation fragments in two
+// halves (P1, and P2 for use in P3/P4).
+//
+// Staging. A K-tile is four 16-KiB "halves" (W0, W1, X0, X1); each wave moves one 2-KiB
+// slice of a half with two LDS-DMA instructions. One half is issued per phase, running
+// ahead of the math:
+//     P1(t): X1(t+1)   P2(t): W0(t+2)   P3(t): W1(t+2)   P4(t): X0(t+2)
+// Each phase is R (LDS reads, DMA issue, waits) | barrier | M (16 MFMAs) | barrier, and waves
+// 4-7 run one barrier behind waves 0-3, so on every SIMD one wave is in M while its partner
+// is in R. A region is re-staged only after a barrier that follows the retirement
+// (lgkmcnt(0)) of its last readers in BOTH groups (W regions are last read in P1, X regions
+// in P2). In P4's R part a wave waits with vmcnt(6): everything but the three newest halves
+// -- i.e. all of K-tile t+1 -- has landed; two barriers later the leading group reads it.
+// The LDS-DMA queue is never drained inside the loop.
+#include "gemm_common.h"
+
+namespace {
+
+constexpr int G2_BN = 256, G2_BM = 256, G2_BK = 64;
+constexpr int G2_STAGE = 64 * 1024;   // W image 32 KiB + X image 32 KiB
+constexpr int G2_XOFF = 32 * 1024;
+constexpr int G2_BAND = 4;
+
+struct G2Ctx {
+  const bf16_t* __restrict__ Wp;
+  const bf16_t* __restrict__ X;
+  char* smem;
+  int nt0, m0, M, K, KT, nk, wave, lane;
+};
+
+// Issues this wave's two 1-KiB pieces of half `which` (0:W0 1:W1 2:X0 3:X1) of K-tile kt_tile.
+LC_DEVICE void g2_issue_half(const G2Ctx& c, int k_tile, int which) {
+  if (k_tile >= c.nk) return;
+  char* stage = c.smem + (k_tile & 1) * G2_STAGE;
+  const int kt0 = k_tile * 2;
+  const int tile = (which & 1) * 8 + c.wave;  // 16-row tile inside the 256-row operand panel
+  if (which < 2) {
+    const bf16_t* src = c.Wp + (static_cast<size_t>(c.nt0 + tile) * c.KT + kt0) * 512 + c.lane * 8;
+    char* dst = stage + (tile * 2) * 1024;
+    __builtin_amdgcn_global_load_lds(LC_GLOBAL_PTR(src), LC_LDS_PTR(dst), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds(LC_GLOBAL_PTR(src + 512), LC_LDS_PTR(dst + 1024), 16, 0, 0);
+  } else {
+    int row = c.m0 + tile * 16 + (c.lane & 15);
+    row = row < c.M ? row : c.M - 1;
+    const bf16_t* src = c.X + static_cast<size_t>(row) * c.K + kt0 * 32 + 8 * (c.lane >> 4);
+    char* dst = stage + G2_XOFF + (tile * 2) * 1024;
+    __builtin_amdgcn_global_load_lds(LC_GLOBAL_PTR(src), LC_LDS_PTR(dst), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds(LC_GLOBAL_PTR(src + 32), LC_LDS_PTR(dst + 1024), 16, 0, 0);
+  }
+}
+
+#define G2_MFMA_QUADRANT(NLO, BFR, MLO)                                                              \
+  do {                                                                                               \
+    __builtin_amdgcn_s_setprio(1);                                                                   \
+    _Pragma("unroll") for (int kt = 0; kt < 2; ++kt)                                                 \
+      _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                  \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                \
+          acc[(NLO) + i][(MLO) + j] =                                                                \
+              __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[(NLO) + i][kt], BFR[j][kt], acc[(NLO) + i][(MLO) + j], 0, 0, 0); \
+    __builtin_amdgcn_s_setprio(0);                                                                   \
+  } while (0)
+
+#define G2_BARRIER()                         \
+  do {                                       \
+    asm volatile("" ::: "memory");           \
+    __builtin_amdgcn_s_barrier();            \
+    asm volatile("" ::: "memory");           \
+  } while (0)
+
+template <int EPI>
+__global__ __launch_bounds__(512) void gemm256_kernel(const bf16_t* __restrict__ Wp,
+                                                      const bf16_t* __restrict__ X, void* __restrict__ Y,
+                                                      const bf16_t* __restrict__ bias, int M, int N, int K,
+                                                      int ldy, int tiles_m, int tiles_n) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wn = wave & 3, wm = wave >> 2;
+
+  // XCD-aware remap (blocks b and b+8 share an XCD): each XCD gets a contiguous run of tiles.
+  const int nwg = tiles_m * tiles_n;
+  const int orig = blockIdx.x;
+  const int xcd = orig & 7, q = nwg >> 3, r = nwg & 7;
+  const int tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+  // Tiles are ordered in bands of G2_BAND n-tiles, n fastest inside a band: the ~32 tiles an
+  // XCD runs at once then form an 8(m) x 4(n) patch that shares 8 activation and 4 weight
+  // panels through that XCD's L2 instead of streaming 32 different activation panels.
+  const int band = tile / (G2_BAND * tiles_m), idx = tile % (G2_BAND * tiles_m);
+  const int bw = min(G2_BAND, tiles_n - band * G2_BAND);
+  const int tn = band * G2_BAND + idx % bw, tm = idx / bw;
+
+  G2Ctx c{Wp, X, smem, tn * (G2_BN / 16), tm * G2_BM, M, K, K / 32, K / G2_BK, wave, lane};
+
+  f32x4 acc[4][8];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  bf16x8 a[4][2], b0[4][2], b1[4][2];
+
+  // ---- prologue: K-tile 0 completely, plus the three halves of K-tile 1 that steady state
+  //      expects to be in flight at the top of a K-tile ----
+#pragma unroll
+  for (int h = 0; h < 4; ++h) g2_issue_half(c, 0, h);
+  g2_issue_half(c, 1, 0);
+  g2_issue_half(c, 1, 1);
+  g2_issue_half(c, 1, 2);
+  if (c.nk > 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+
+  // Stagger: waves 4-7 (the SIMD partners of waves 0-3) run half a phase behind, so one
+  // partner's LDS reads / DMA issue ("R") always overlap the other's 16 MFMAs ("M").
+  if (wave >= 4) G2_BARRIER();
+
+  for (int t = 0; t < c.nk; ++t) {
+    const char* wimg = smem + (t & 1) * G2_STAGE + (wn * 4 * 2) * 1024 + lane * 16;
+    const char* ximg = smem + (t & 1) * G2_STAGE + G2_XOFF + (wm * 8 * 2) * 1024 + lane * 16;
+    // ---------------- P1 ----------------
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt) a[i][kt] = *reinterpret_cast<const bf16x8*>(wimg + (i * 2 + kt) * 1024);
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt) b0[j][kt] = *reinterpret_cast<const bf16x8*>(ximg + (j * 2 + kt) * 1024);
+    g2_issue_half(c, t + 1, 3);
+    // Reads are retired BEFORE the barrier: the W regions are re-staged by the other wave
+    // group in the very next slot.
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    G2_BARRIER();
+    G2_MFMA_QUADRANT(0, b0, 0);
+    G2_BARRIER();
+    // ---------------- P2 ----------------
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt)
+        b1[j][kt] = *reinterpret_cast<const bf16x8*>(ximg + ((4 + j) * 2 + kt) * 1024);
+    g2_issue_half(c, t + 2, 0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    G2_BARRIER();
+    G2_MFMA_QUADRANT(2, b0, 0);
+    G2_BARRIER();
+    // ---------------- P3 ----------------
+    g2_issue_half(c, t + 2, 1);
+    G2_BARRIER();
+    G2_MFMA_QUADRANT(2, b1, 4);
+    G2_BARRIER();
+    // ---------------- P4 ----------------
+    g2_issue_half(c, t + 2, 2);
+    // The wait sits before P4's FIRST barrier: the lagging group's wait must be over one
+    // barrier before the leading group starts reading K-tile t+1.
+    if (t + 2 < c.nk) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    G2_BARRIER();
+    G2_MFMA_QUADRANT(0, b1, 4);
+    G2_BARRIER();
+  }
+  if (wave < 4) G2_BARRIER();  // balance the stagger barrier
+
+  const int nbase = tn * G2_BN + wn * 64, mbase = c.m0 + wm * 128;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      if constexpr (EPI == EPI_SWIGLU) {
+        if (i & 1) continue;
+        store_tile<EPI>(acc[i][j], &acc[i + 1][j], Y, bias, mbase + j * 16, nbase + i * 16, M, N, ldy, lane, 0);
+      } else {
+        store_tile<EPI>(acc[i][j], nullptr, Y, bias, mbase + j * 16, nbase + i * 16, M, N, ldy, lane, 0);
+      }
+    }
+}
+
+}  // namespace
+
+// Y = X * W^T with the 256x256 pipelined tile. Requirements: K % 64 == 0, n_pad % 256 == 0.
+LC_EXPORT int lc_gemm256(const void* Wp, const void* X, void* Y, const void* bias, int M, int N, int K,
+                         int n_pad, int ldy, int epi, hipStream_t stream) {
+  if (M <= 0) return 0;
+  if (K % 64 || n_pad % 256 || N > n_pad) return -1;
+  const int tiles_m = (M + G2_BM - 1) / G2_BM, tiles_n = n_pad / G2_BN;
+  const dim3 grid(tiles_m * tiles_n), block(512);
+  const size_t lds = 2 * G2_STAGE;
+  auto w = static_cast<const bf16_t*>(Wp);
+  auto x = static_cast<const bf16_t*>(X);
+  auto b = static_cast<const bf16_t*>(bias);
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256_kernel<EPI_BF16>),
+                        hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+    hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256_kernel<EPI_F32>),
+                        hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+    hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256_kernel<EPI_SWIGLU>),
+                        hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+    attr_set = true;
+  }
+  if (epi == EPI_BF16)
+    gemm256_kernel<EPI_BF16><<<grid, block, lds, stream>>>(w, x, Y, b, M, N, K, ldy, tiles_m, tiles_n);
+  else if (epi == EPI_F32)
+    gemm256_kernel<EPI_F32><<<grid, block, lds, stream>>>(w, x, Y, b, M, N, K, ldy, tiles_m, tiles_n);
+  else if (epi == EPI_SWIGLU)
+    gemm256_kernel<EPI_SWIGLU><<<grid, block, lds, stream>>>(w, x, Y, b, M, N, K, ldy, tiles_m, tiles_n);
+  else
+    return -2;
+  LC_RETURN_LAST_ERROR();
+}

@@ -19,6 +19,9 @@ EPI_BF16, EPI_F32, EPI_SWIGLU = 0, 1, 2
 
 # M at or below which the weight-streaming kernel is used instead of the 128x128 tile kernel.
 WS_MAX_M = int(os.environ.get("LC_WS_MAX_M", "256"))
+# The 256x256 pipelined kernel runs one workgroup per CU: use it once a launch has at least this
+# many 256x256 tiles (fewer tiles leave CUs idle; the 128x128 kernel fills the chip better). -1 disables.
+GEMM256_MIN_TILES = int(os.environ.get("LC_GEMM256_MIN_TILES", "192"))
 # Target number of workgroups for the weight-streaming kernel (256 CUs on MI355X).
 WS_TARGET_BLOCKS = int(os.environ.get("LC_WS_TARGET_BLOCKS", "256"))
 
@@ -126,6 +129,11 @@ def linear(x: torch.Tensor, w: LinearWeight, out_f32: bool = False) -> torch.Ten
     if M == 0:
         return y
     if M > WS_MAX_M:
+        tiles256 = ((M + 255) // 256) * (w.n_pad // 256)
+        if GEMM256_MIN_TILES >= 0 and w.n_pad % 256 == 0 and tiles256 >= GEMM256_MIN_TILES:
+            h.call("lc_gemm256", w.data.data_ptr(), x.data_ptr(), y.data_ptr(), h.ptr(w.bias), M, w.n, w.k, w.n_pad,
+                   out_n, epi)
+            return y
         h.call("lc_gemm_tile", w.data.data_ptr(), x.data_ptr(), y.data_ptr(), h.ptr(w.bias), M, w.n, w.k, w.n_pad,
                out_n, epi)
         return y

@@ -47,16 +47,44 @@ def test_gemm_tile(M, N, K, bias):
     W = bf(rand(N, K, scale=0.5, seed=1) + torch.arange(N)[:, None] * 1e-3)
     b = bf(rand(N, seed=2)) if bias else None
     lw = ops.LinearWeight.from_dense(W, b, DEV)
-    old = ops.WS_MAX_M
-    ops.WS_MAX_M = 0
+    old = ops.WS_MAX_M, ops.GEMM256_MIN_TILES
+    ops.WS_MAX_M, ops.GEMM256_MIN_TILES = 0, -1
     try:
         y = ops.linear(X.to(DEV), lw)
         y32 = ops.linear(X.to(DEV), lw, out_f32=True)
     finally:
-        ops.WS_MAX_M = old
+        ops.WS_MAX_M, ops.GEMM256_MIN_TILES = old
     want = ref.linear(X, W, b, torch.float32)
     assert rel_err(y, want) < 6e-3
     assert rel_err(y32, want) < 1e-4
+
+
+@pytest.mark.parametrize("M,N,K", [(256, 256, 64), (512, 512, 128), (700, 256, 4096), (1000, 1024, 896), (257, 768, 1024)])
+@pytest.mark.parametrize("mode", ["bf16", "f32_bias", "swiglu"])
+def test_gemm256_pipelined(M, N, K, mode):
+    """256x256 LDS-DMA pipelined kernel; K from 1 to 64 K-tiles exercises prologue, steady
+    state and drain; run twice to catch a race that only shows on warm caches."""
+    X = bf(rand(M, K, scale=0.5) + torch.arange(M)[:, None] * 1e-3)
+    old = ops.GEMM256_MIN_TILES, ops.WS_MAX_M
+    ops.GEMM256_MIN_TILES, ops.WS_MAX_M = 0, 0
+    try:
+        if mode == "swiglu":
+            Wg, Wu = bf(rand(N // 2, K, scale=0.3, seed=3)), bf(rand(N // 2, K, scale=0.3, seed=4))
+            lw = ops.LinearWeight.from_dense(ops.interleave_gate_up(Wg, Wu), None, DEV, swiglu=True)
+            want = torch.nn.functional.silu(X.float() @ Wg.float().t()) * (X.float() @ Wu.float().t())
+            tol = 8e-3
+        else:
+            W = bf(rand(N, K, scale=0.5, seed=1) + torch.arange(N)[:, None] * 1e-3)
+            b = bf(rand(N, seed=2)) if mode == "f32_bias" else None
+            lw = ops.LinearWeight.from_dense(W, b, DEV)
+            want = ref.linear(X, W, b, torch.float32)
+            tol = 1e-4 if mode == "f32_bias" else 6e-3
+        xg = X.to(DEV)
+        for _ in range(3):
+            got = ops.linear(xg, lw, out_f32=(mode == "f32_bias"))
+            assert rel_err(got, want) < tol
+    finally:
+        ops.GEMM256_MIN_TILES, ops.WS_MAX_M = old
 
 
 @pytest.mark.parametrize("M", [1, 7, 16, 33, 64, 100, 128, 200, 256])
