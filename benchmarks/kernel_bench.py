@@ -54,9 +54,13 @@ def bench_gemm(results):
                 continue
             X = (torch.randn(M, K, device=DEV) * 0.5).bfloat16()
             row = {"op": "linear", "M": M, "N": N, "K": K}
-            for name, ws_max, g256 in (("ws", 256, -1), ("tile", 0, -1), ("g256", 0, 0)):
-                if name == "ws" and M > 256:
+            for name, ws_max, g256 in (("ws", 256, -1), ("k1", 256, -1), ("k2", 256, -1), ("k4", 256, -1),
+                                       ("tile", 0, -1), ("g256", 0, 0)):
+                if name in ("ws", "k1", "k2", "k4") and M > 256:
                     continue
+                if name[0] == "k" and (M > 64 or N > 40960):
+                    continue
+                ops.KGEMM_FORCE_NTW = int(name[1]) if name[0] == "k" else 0
                 if name == "g256" and (M < 256 or lw.n_pad % 256):
                     continue
                 ops.WS_MAX_M, ops.GEMM256_MIN_TILES = ws_max, g256
@@ -68,7 +72,7 @@ def bench_gemm(results):
                 row[name + "_us"] = round(us, 2)
                 row[name + "_tflops"] = round(2 * M * N * K / us / 1e6, 1)
                 row[name + "_gbs"] = round((N * K * 2 + M * K * 2 + M * N * 2) / us / 1e3, 1)
-            ops.WS_MAX_M, ops.GEMM256_MIN_TILES = 256, 192
+            ops.WS_MAX_M, ops.GEMM256_MIN_TILES, ops.KGEMM_FORCE_NTW = 256, 192, -1
             us = timeit(lambda: X @ W.t())
             row["torch_us"] = round(us, 2)
             row["torch_tflops"] = round(2 * M * N * K / us / 1e6, 1)

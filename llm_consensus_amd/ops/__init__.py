@@ -22,6 +22,11 @@ WS_MAX_M = int(os.environ.get("LC_WS_MAX_M", "256"))
 # The 256x256 pipelined kernel runs one workgroup per CU: use it once a launch has at least this
 # many 256x256 tiles (fewer tiles leave CUs idle; the 128x128 kernel fills the chip better). -1 disables.
 GEMM256_MIN_TILES = int(os.environ.get("LC_GEMM256_MIN_TILES", "192"))
+# In-workgroup K-split decode kernel (kgemm.hip): widest output it is used for, and a test override
+# (-1 = automatic, 0 = never, 1/2/4 = force that many n-tiles per workgroup).
+KGEMM_MAX_N = int(os.environ.get("LC_KGEMM_MAX_N", "8192"))
+KGEMM_MAX_M = int(os.environ.get("LC_KGEMM_MAX_M", "16"))   # measured: beyond 16 rows the weight-streaming kernel wins
+KGEMM_FORCE_NTW = int(os.environ.get("LC_KGEMM_NTW", "-1"))
 # Target number of workgroups for the weight-streaming kernel (256 CUs on MI355X).
 WS_TARGET_BLOCKS = int(os.environ.get("LC_WS_TARGET_BLOCKS", "256"))
 
@@ -94,6 +99,22 @@ class LinearWeight:
         return self.data.numel() * self.data.element_size() + (self.bias.numel() * 2 if self.bias is not None else 0)
 
 
+def _kgemm_ntw(n_pad: int, M: int, swiglu: bool) -> int:
+    """n-tiles per workgroup for the in-workgroup K-split kernel, or 0 to use another kernel.
+    It re-reads the activations once per workgroup from L2, so it is limited to M <= 64 and
+    to outputs narrow enough that this stays below the weight traffic."""
+    if KGEMM_FORCE_NTW >= 0:
+        return KGEMM_FORCE_NTW if M <= 64 else 0
+    if M > KGEMM_MAX_M or n_pad > KGEMM_MAX_N:
+        return 0
+    for ntw in (4, 2, 1):
+        if swiglu and ntw < 2:
+            break
+        if n_pad // (16 * ntw) >= 256:
+            return ntw
+    return 2 if swiglu else 1
+
+
 def _choose_splits(n_pad: int, K: int, M: int, allow: bool) -> int:
     if not allow:
         return 1
@@ -136,6 +157,11 @@ def linear(x: torch.Tensor, w: LinearWeight, out_f32: bool = False) -> torch.Ten
             return y
         h.call("lc_gemm_tile", w.data.data_ptr(), x.data_ptr(), y.data_ptr(), h.ptr(w.bias), M, w.n, w.k, w.n_pad,
                out_n, epi)
+        return y
+    ntw = _kgemm_ntw(w.n_pad, M, w.swiglu)
+    if ntw:
+        h.call("lc_kgemm", w.data.data_ptr(), x.data_ptr(), y.data_ptr(), h.ptr(w.bias), M, w.n, w.k, w.n_pad,
+               out_n, epi, ntw)
         return y
     splits = _choose_splits(w.n_pad, w.k, M, allow=True)
     if splits == 1:

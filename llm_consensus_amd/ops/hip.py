@@ -26,6 +26,7 @@ _SIGNATURES = {
     "lc_gemm_tile": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "lc_gemm256": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "lc_wsgemm": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
+    "lc_kgemm": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
     "lc_splitk_reduce": [_P, _P, _P, _I, _I, _I, _I, _I, _P],
     "lc_gemm_grouped": [_P, _L, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _P],
     "lc_rope_kv_write": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],

@@ -87,6 +87,29 @@ def test_gemm256_pipelined(M, N, K, mode):
         ops.GEMM256_MIN_TILES, ops.WS_MAX_M = old
 
 
+@pytest.mark.parametrize("M", [1, 16, 17, 33, 64])
+@pytest.mark.parametrize("N,K", [(256, 1024), (1152, 896), (128, 4096), (384, 192)])
+@pytest.mark.parametrize("ntw", [1, 2, 4])
+def test_kgemm_in_workgroup_ksplit(M, N, K, ntw):
+    X = bf(rand(M, K, scale=0.5) + torch.arange(M)[:, None] * 1e-3)
+    W = bf(rand(N, K, scale=0.5, seed=1) + torch.arange(N)[:, None] * 1e-3)
+    b = bf(rand(N, seed=2))
+    lw = ops.LinearWeight.from_dense(W, b, DEV)
+    want = ref.linear(X, W, b, torch.float32)
+    old = ops.KGEMM_FORCE_NTW
+    ops.KGEMM_FORCE_NTW = ntw
+    try:
+        assert rel_err(ops.linear(X.to(DEV), lw), want) < 6e-3
+        assert rel_err(ops.linear(X.to(DEV), lw, out_f32=True), want) < 1e-4
+        if ntw >= 2:
+            Wg, Wu = bf(rand(N // 2, K, scale=0.3, seed=3)), bf(rand(N // 2, K, scale=0.3, seed=4))
+            lws = ops.LinearWeight.from_dense(ops.interleave_gate_up(Wg, Wu), None, DEV, swiglu=True)
+            wants = torch.nn.functional.silu(X.float() @ Wg.float().t()) * (X.float() @ Wu.float().t())
+            assert rel_err(ops.linear(X.to(DEV), lws), wants) < 8e-3
+    finally:
+        ops.KGEMM_FORCE_NTW = old
+
+
 @pytest.mark.parametrize("M", [1, 7, 16, 33, 64, 100, 128, 200, 256])
 @pytest.mark.parametrize("N,K", [(256, 1024), (1152, 896), (128, 4096)])
 def test_wsgemm_with_and_without_splitk(M, N, K):
@@ -96,6 +119,8 @@ def test_wsgemm_with_and_without_splitk(M, N, K):
     lw = ops.LinearWeight.from_dense(W, b, DEV)
     want = ref.linear(X, W, b, torch.float32)
     old = ops.WS_MAX_M, ops.WS_TARGET_BLOCKS
+    old_k = ops.KGEMM_FORCE_NTW
+    ops.KGEMM_FORCE_NTW = 0
     try:
         ops.WS_MAX_M = 256
         for target in (1, 4096):      # 1 => no split-K, 4096 => as many splits as allowed
@@ -104,6 +129,7 @@ def test_wsgemm_with_and_without_splitk(M, N, K):
             assert rel_err(ops.linear(X.to(DEV), lw, out_f32=True), want) < 1e-4
     finally:
         ops.WS_MAX_M, ops.WS_TARGET_BLOCKS = old
+        ops.KGEMM_FORCE_NTW = old_k
 
 
 @pytest.mark.parametrize("M", [5, 64, 128, 400])
