@@ -167,7 +167,7 @@ LC_DEVICE void finish_and_store(AttnState<DH>& st, bf16_t* out_bf16, float* out_
 // ------------------------------------------------------------------ prefill
 // grid (q_tile, kv_head, seq); block = G waves (G = Hq/Hkv), wave g = q-head kvh*G+g.
 template <int DH>
-__global__ void attn_prefill_kernel(const bf16_t* __restrict__ Q, int q_stride,
+__global__ __launch_bounds__(512) void attn_prefill_kernel(const bf16_t* __restrict__ Q, int q_stride,
                                     const bf16_t* __restrict__ Kc, const bf16_t* __restrict__ Vt,
                                     const int32_t* __restrict__ block_tables, int max_blocks,
                                     const int32_t* __restrict__ cu_q, const int32_t* __restrict__ ctx_lens,
@@ -210,7 +210,7 @@ __global__ void attn_prefill_kernel(const bf16_t* __restrict__ Q, int q_stride,
 // 0..G-1 carry the G query heads of this kv head. Keys [kv_begin[b], ctx_len[b]) are cut
 // into `nsplit` ranges. With partials == nullptr (nsplit == 1) the bf16 output is final.
 template <int DH>
-__global__ void attn_decode_kernel(const bf16_t* __restrict__ Q, int q_stride,
+__global__ __launch_bounds__(64) void attn_decode_kernel(const bf16_t* __restrict__ Q, int q_stride,
                                    const bf16_t* __restrict__ Kc, const bf16_t* __restrict__ Vt,
                                    const int32_t* __restrict__ block_tables, int max_blocks,
                                    const int32_t* __restrict__ ctx_lens, const int32_t* __restrict__ kv_begin,
@@ -256,7 +256,7 @@ __global__ void attn_decode_kernel(const bf16_t* __restrict__ Q, int q_stride,
 // grid (row_tile, kv_head, group*nsplit + split); block = 1 wave. Writes partial slots
 // [slot0 + split].
 template <int DH>
-__global__ void attn_prefix_kernel(const bf16_t* __restrict__ Q, int q_stride,
+__global__ __launch_bounds__(64) void attn_prefix_kernel(const bf16_t* __restrict__ Q, int q_stride,
                                    const bf16_t* __restrict__ Kc, const bf16_t* __restrict__ Vt,
                                    const int32_t* __restrict__ block_tables, int max_blocks,
                                    const int32_t* __restrict__ group_first,
@@ -340,7 +340,7 @@ LC_EXPORT int lc_attn_prefill(const void* Q, int q_stride, const void* Kc, const
                               const void* ctx_lens, void* out, int n_seqs, int max_q_len, int Hq, int Hkv,
                               int Dh, int block_size, float scale, int window, hipStream_t stream) {
   if (n_seqs <= 0 || max_q_len <= 0) return 0;
-  if (Hq % Hkv || Hq / Hkv > 16 || (Dh != 64 && Dh != 128) || block_size % 8 ||
+  if (Hq % Hkv || Hq / Hkv > 8 || (Dh != 64 && Dh != 128) || block_size % 8 ||
       (block_size & (block_size - 1)))
     return -1;
   const dim3 grid((max_q_len + 31) / 32, Hkv, n_seqs), block(64 * (Hq / Hkv));

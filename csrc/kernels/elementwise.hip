@@ -23,6 +23,8 @@ __global__ void embed_gather_kernel(const int32_t* __restrict__ ids, const bf16_
 
 // If `delta` != nullptr: h += delta (h is the bf16 residual stream, updated in place),
 // then y = h * rsqrt(mean(h^2) + eps) * w. With delta == nullptr it is a plain RMSNorm of h.
+// One wave per row; the row stays in registers as packed bf16 (CH chunks of 8 per lane).
+template <int CH>
 __global__ void rmsnorm_kernel(bf16_t* __restrict__ h, const bf16_t* __restrict__ delta,
                                const bf16_t* __restrict__ w, bf16_t* __restrict__ y, int T, int d,
                                float eps) {
@@ -32,44 +34,42 @@ __global__ void rmsnorm_kernel(bf16_t* __restrict__ h, const bf16_t* __restrict_
   const int nchunk = d / 8;
   bf16_t* hrow = h + static_cast<size_t>(row) * d;
   const bf16_t* drow = delta ? delta + static_cast<size_t>(row) * d : nullptr;
-  float v[kMaxChunksPerLane][8];
+  bf16x8 v[CH];
   float ss = 0.f;
 #pragma unroll
-  for (int i = 0; i < kMaxChunksPerLane; ++i) {
+  for (int i = 0; i < CH; ++i) {
     const int c = lane + i * 64;
     if (c < nchunk) {
       bf16x8 a = *reinterpret_cast<const bf16x8*>(hrow + c * 8);
       if (drow) {
-        bf16x8 b = *reinterpret_cast<const bf16x8*>(drow + c * 8);
-        bf16x8 o;
+        const bf16x8 b = *reinterpret_cast<const bf16x8*>(drow + c * 8);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          float s = bf16_to_f32(static_cast<bf16_t>(a[j])) + bf16_to_f32(static_cast<bf16_t>(b[j]));
-          bf16_t r = f32_to_bf16(s);
-          o[j] = static_cast<short>(r);
-          v[i][j] = bf16_to_f32(r);  // normalise exactly what the residual stream now holds
-        }
-        *reinterpret_cast<bf16x8*>(hrow + c * 8) = o;
-      } else {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) v[i][j] = bf16_to_f32(static_cast<bf16_t>(a[j]));
+        for (int j = 0; j < 8; ++j)
+          a[j] = static_cast<short>(f32_to_bf16(bf16_to_f32(static_cast<bf16_t>(a[j])) +
+                                                bf16_to_f32(static_cast<bf16_t>(b[j]))));
+        *reinterpret_cast<bf16x8*>(hrow + c * 8) = a;
       }
+      v[i] = a;  // normalise exactly what the residual stream now holds
 #pragma unroll
-      for (int j = 0; j < 8; ++j) ss += v[i][j] * v[i][j];
+      for (int j = 0; j < 8; ++j) {
+        const float f = bf16_to_f32(static_cast<bf16_t>(a[j]));
+        ss += f * f;
+      }
     }
   }
   ss = wave_sum(ss);
   const float scale = rsqrtf(ss / static_cast<float>(d) + eps);
   bf16_t* yrow = y + static_cast<size_t>(row) * d;
 #pragma unroll
-  for (int i = 0; i < kMaxChunksPerLane; ++i) {
+  for (int i = 0; i < CH; ++i) {
     const int c = lane + i * 64;
     if (c < nchunk) {
-      bf16x8 g = *reinterpret_cast<const bf16x8*>(w + c * 8);
+      const bf16x8 g = *reinterpret_cast<const bf16x8*>(w + c * 8);
       bf16x8 o;
 #pragma unroll
       for (int j = 0; j < 8; ++j)
-        o[j] = static_cast<short>(f32_to_bf16(v[i][j] * scale * bf16_to_f32(static_cast<bf16_t>(g[j]))));
+        o[j] = static_cast<short>(f32_to_bf16(bf16_to_f32(static_cast<bf16_t>(v[i][j])) * scale *
+                                              bf16_to_f32(static_cast<bf16_t>(g[j]))));
       *reinterpret_cast<bf16x8*>(yrow + c * 8) = o;
     }
   }
@@ -165,9 +165,15 @@ LC_EXPORT int lc_rmsnorm(void* h, const void* delta, const void* w, void* y, int
                          hipStream_t stream) {
   if (T <= 0) return 0;
   if (d % 8 || d > kMaxChunksPerLane * 64 * 8) return -1;
-  rmsnorm_kernel<<<dim3((T + 3) / 4), dim3(256), 0, stream>>>(
-      static_cast<bf16_t*>(h), static_cast<const bf16_t*>(delta), static_cast<const bf16_t*>(w),
-      static_cast<bf16_t*>(y), T, d, eps);
+  const dim3 grid((T + 3) / 4), block(256);
+#define LC_RMS(CH)                                                                               \
+  rmsnorm_kernel<CH><<<grid, block, 0, stream>>>(static_cast<bf16_t*>(h), static_cast<const bf16_t*>(delta), \
+                                                 static_cast<const bf16_t*>(w), static_cast<bf16_t*>(y), T, d, eps)
+  if (d <= 2 * 512) LC_RMS(2);
+  else if (d <= 4 * 512) LC_RMS(4);
+  else if (d <= 8 * 512) LC_RMS(8);
+  else LC_RMS(16);
+#undef LC_RMS
   LC_RETURN_LAST_ERROR();
 }
 
