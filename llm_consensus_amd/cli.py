@@ -1,0 +1,117 @@
+"""Interactive front end: ``python -m llm_consensus_amd.cli [--config FILE]``.
+
+Same loop as the reference's ``main`` (/root/reference/src/main.rs:428-471): print
+``Enter a question: ``, read one line, ``exit`` leaves, anything else is put to the
+ensemble; afterwards the session state is reset and the prompt returns. Differences:
+
+* the answer is written to stdout (the reference only logs it at info level,
+  main.rs:464, so it is invisible without ``RUST_LOG=info``);
+* there is no readiness poll: the reference spins on ``AnswerReadinessRequest`` every
+  500 ms (main.rs:448-459) because its coordinator is an actor; here ``ask`` returns when
+  the session has finished;
+* end-of-file on stdin ends the loop (the reference would spin on empty questions);
+* no API key is needed: the members run on local GPUs (main.rs:354-357 checks
+  ``GEMINI_API_KEY``). ``CONSENSUS_CONFIG`` / ``--config`` select the ensemble and
+  ``CONSENSUS_LOG`` (or ``RUST_LOG``) the log level.
+
+``--questions FILE`` answers a file of questions (one per line) as one batch instead of
+reading stdin, and ``--json`` prints one JSON object per answer with votes, rounds and
+latency.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import sys
+from typing import Iterable, Optional, TextIO
+
+from .config import ConsensusConfig, load_config
+from .utils.log import get_logger
+
+PROMPT = "Enter a question: "
+log = get_logger("consensus.cli")
+
+
+def result_record(res) -> dict:
+    return {
+        "question": res.question,
+        "answer": res.answer,
+        "strategy": res.strategy,
+        "rounds": res.rounds,
+        "member_calls": res.member_calls,
+        "unanimous": res.unanimous,
+        "agreement": getattr(res, "agreement", None),
+        "latency_s": round(res.latency_s, 6),
+        "votes": getattr(res, "votes", None),
+    }
+
+
+def repl(ensemble, stdin: Optional[TextIO] = None, stdout: Optional[TextIO] = None, as_json: bool = False) -> int:
+    """Runs the question loop until ``exit`` or end of input; returns the number of
+    questions answered."""
+    stdin, stdout = stdin or sys.stdin, stdout or sys.stdout
+    answered = 0
+    while True:
+        stdout.write(PROMPT)
+        stdout.flush()
+        line = stdin.readline()
+        if not line:
+            stdout.write("\n")
+            break
+        question = line.strip()
+        if question == "exit":
+            break
+        if not question:
+            continue
+        try:
+            res = ensemble.ask(question)
+        except Exception as e:  # a failed session must not take the loop down
+            log.error("session failed: %s", e)
+            stdout.write(f"System error: {e}\n")
+            continue
+        log.info("Final answer: %s", res.answer)
+        stdout.write((json.dumps(result_record(res)) if as_json else res.answer) + "\n")
+        stdout.flush()
+        answered += 1
+    return answered
+
+
+def answer_file(ensemble, questions: Iterable[str], stdout: Optional[TextIO] = None, as_json: bool = False) -> int:
+    stdout = stdout or sys.stdout
+    qs = [q.strip() for q in questions if q.strip()]
+    for res in ensemble.ask_many(qs):
+        stdout.write((json.dumps(result_record(res)) if as_json else res.answer) + "\n")
+    stdout.flush()
+    return len(qs)
+
+
+def main(argv: Optional[list] = None) -> int:
+    ap = argparse.ArgumentParser(prog="llm-consensus", description=__doc__.split("\n\n")[0])
+    ap.add_argument("--config", help="TOML/JSON/YAML ensemble description (default: $CONSENSUS_CONFIG, "
+                                     "else four personas on one built-in model)")
+    ap.add_argument("--questions", help="answer the questions of this file (one per line) as one batch")
+    ap.add_argument("--json", action="store_true", help="print one JSON record per answer")
+    ap.add_argument("--strategy", help="override the configured strategy")
+    ap.add_argument("--device", help="cuda[:N] or cpu (default: GPU when present)")
+    args = ap.parse_args(argv)
+
+    cfg: ConsensusConfig = load_config(args.config)
+    if args.strategy:
+        cfg.strategy = args.strategy
+        cfg.validate()
+    import torch
+
+    from .app import build_ensemble
+
+    device = torch.device(args.device) if args.device else None
+    ensemble = build_ensemble(cfg, device)
+    if args.questions:
+        with open(args.questions) as f:
+            answer_file(ensemble, f, as_json=args.json)
+    else:
+        repl(ensemble, as_json=args.json)
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

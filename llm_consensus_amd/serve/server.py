@@ -1,0 +1,398 @@
+"""OpenAI-compatible HTTP front door for an ensemble.
+
+The reference's only interface is a stdin REPL (/root/reference/src/main.rs:428-471) that
+serves one question at a time. A deployment needs a network endpoint and, more
+importantly for throughput, a place where concurrent callers are merged into engine
+batches. This module provides both with the standard library only:
+
+    handler threads (ThreadingHTTPServer)  --jobs-->  one driver thread
+                                                      collects up to ``max_batch`` jobs for
+                                                      ``batch_window_ms``, answers them with
+                                                      ONE ensemble.ask_many / backend.run,
+                                                      wakes the handlers.
+
+All GPU work happens on the driver thread, so engines never see concurrent callers.
+
+Routes
+    GET  /health                 liveness + queue depth
+    GET  /v1/models              "consensus" plus every member model
+    GET  /metrics                Prometheus text (server counters, engine stats)
+    POST /v1/chat/completions    model "consensus" (default) runs the configured strategy on
+                                 the last user message; any other model name is served by
+                                 that member model directly (n, max_tokens, temperature,
+                                 top_p, seed honoured). ``stream: true`` yields SSE chunks.
+    POST /v1/completions         same for a raw prompt
+    POST /v1/embeddings          pooled, L2-normalised embeddings from a member model
+Consensus responses carry an extra ``consensus`` object (votes, rounds, agreement,
+unanimity) next to the OpenAI fields.
+"""
+from __future__ import annotations
+
+import json
+import queue
+import threading
+import time
+import uuid
+from dataclasses import dataclass, field
+from http.server import BaseHTTPRequestHandler, ThreadingHTTPServer
+from typing import Any, Dict, List, Optional
+
+from ..consensus.backend import BackendError, GenParams
+from ..utils.log import get_logger
+
+log = get_logger("consensus.serve")
+CONSENSUS_MODEL = "consensus"
+
+
+@dataclass
+class _Job:
+    kind: str                      # consensus | generate | embed
+    model: str
+    text: str
+    params: Optional[GenParams] = None
+    done: threading.Event = field(default_factory=threading.Event)
+    result: Any = None
+    error: Optional[str] = None
+    t_submit: float = field(default_factory=time.perf_counter)
+
+
+class HTTPError(Exception):
+    def __init__(self, status: int, message: str) -> None:
+        super().__init__(message)
+        self.status, self.message = status, message
+
+
+class ConsensusServer:
+    def __init__(self, ensemble, host: str = "127.0.0.1", port: int = 8000, max_batch: int = 64,
+                 batch_window_ms: float = 5.0, request_timeout_s: float = 600.0) -> None:
+        self.ensemble = ensemble
+        self.max_batch, self.window = max_batch, batch_window_ms / 1e3
+        self.request_timeout_s = request_timeout_s
+        self.jobs: "queue.Queue[_Job]" = queue.Queue()
+        self.counters: Dict[str, float] = {"requests_total": 0, "errors_total": 0, "batches_total": 0,
+                                           "batched_requests_total": 0, "latency_seconds_sum": 0.0}
+        self._lock = threading.Lock()
+        self._stop = threading.Event()
+        server = self
+
+        class Handler(BaseHTTPRequestHandler):
+            protocol_version = "HTTP/1.1"
+
+            def log_message(self, fmt, *args):  # route access logs through our logger
+                log.debug("%s " + fmt, self.address_string(), *args)
+
+            def do_GET(self):
+                server._dispatch(self, "GET")
+
+            def do_POST(self):
+                server._dispatch(self, "POST")
+
+        self.httpd = ThreadingHTTPServer((host, port), Handler)
+        self.httpd.daemon_threads = True
+        self.host, self.port = self.httpd.server_address[:2]
+        self._driver = threading.Thread(target=self._drive, name="consensus-driver", daemon=True)
+        self._http = threading.Thread(target=self.httpd.serve_forever, name="consensus-http", daemon=True)
+
+    # ------------------------------------------------------------------ lifecycle
+    def start(self) -> "ConsensusServer":
+        self._driver.start()
+        self._http.start()
+        log.info("serving on http://%s:%d", self.host, self.port)
+        return self
+
+    def serve_forever(self) -> None:
+        """Runs the engine driver on the calling thread (GPU contexts stay on the main
+        thread) and the HTTP accept loop on a helper thread."""
+        self._http.start()
+        log.info("serving on http://%s:%d", self.host, self.port)
+        try:
+            self._drive()
+        except KeyboardInterrupt:
+            pass
+        finally:
+            self.shutdown()
+
+    def shutdown(self) -> None:
+        self._stop.set()
+        self.httpd.shutdown()
+        self.httpd.server_close()
+        if self._driver.is_alive():
+            self._driver.join(timeout=5)
+
+    # ------------------------------------------------------------------ driver
+    def _collect(self) -> List[_Job]:
+        try:
+            first = self.jobs.get(timeout=0.05)
+        except queue.Empty:
+            return []
+        batch = [first]
+        deadline = time.perf_counter() + self.window
+        while len(batch) < self.max_batch:
+            left = deadline - time.perf_counter()
+            try:
+                batch.append(self.jobs.get(timeout=max(left, 0)) if left > 0 else self.jobs.get_nowait())
+            except queue.Empty:
+                break
+        return batch
+
+    def _drive(self) -> None:
+        while not self._stop.is_set():
+            batch = self._collect()
+            if not batch:
+                continue
+            with self._lock:
+                self.counters["batches_total"] += 1
+                self.counters["batched_requests_total"] += len(batch)
+            try:
+                self._run_batch(batch)
+            except Exception as e:  # never let the driver die with waiters parked on it
+                log.error("batch failed: %s", e)
+                for j in batch:
+                    if not j.done.is_set():
+                        j.error = f"{type(e).__name__}: {e}"
+            for j in batch:
+                j.done.set()
+
+    def _run_batch(self, batch: List[_Job]) -> None:
+        cons = [j for j in batch if j.kind == "consensus"]
+        if cons:
+            for j, res in zip(cons, self.ensemble.ask_many([j.text for j in cons])):
+                j.result = res
+        direct = [j for j in batch if j.kind != "consensus"]
+        handles = []
+        for j in direct:
+            be = self.ensemble.backends[j.model]
+            handles.append(be.submit_embed(j.text) if j.kind == "embed" else be.submit_generate(j.text, j.params))
+        for name in {j.model for j in direct}:
+            self.ensemble.backends[name].run()
+        for j, h in zip(direct, handles):
+            try:
+                j.result = h.result()
+            except BackendError as e:
+                j.error = str(e)
+
+    def submit(self, job: _Job) -> _Job:
+        self.jobs.put(job)
+        if not job.done.wait(self.request_timeout_s):
+            raise HTTPError(504, "request timed out in the engine queue")
+        if job.error:
+            raise HTTPError(500, job.error)
+        return job
+
+    # ------------------------------------------------------------------ http
+    def _dispatch(self, h: BaseHTTPRequestHandler, method: str) -> None:
+        t0 = time.perf_counter()
+        with self._lock:
+            self.counters["requests_total"] += 1
+        try:
+            path = h.path.split("?", 1)[0].rstrip("/") or "/"
+            if method == "GET":
+                if path in ("/health", "/healthz"):
+                    return self._send_json(h, 200, {"status": "ok", "queued": self.jobs.qsize()})
+                if path == "/v1/models":
+                    return self._send_json(h, 200, self._models())
+                if path == "/metrics":
+                    return self._send(h, 200, self._metrics().encode(), "text/plain; version=0.0.4")
+                raise HTTPError(404, f"no route {path}")
+            n = int(h.headers.get("Content-Length") or 0)
+            try:
+                body = json.loads(h.rfile.read(n) or b"{}")
+            except json.JSONDecodeError as e:
+                raise HTTPError(400, f"invalid JSON body: {e}")
+            if path == "/v1/chat/completions":
+                return self._completion(h, body, chat=True)
+            if path == "/v1/completions":
+                return self._completion(h, body, chat=False)
+            if path == "/v1/embeddings":
+                return self._embeddings(h, body)
+            raise HTTPError(404, f"no route {path}")
+        except HTTPError as e:
+            with self._lock:
+                self.counters["errors_total"] += 1
+            self._send_json(h, e.status, {"error": {"message": e.message, "type": "invalid_request_error"
+                                                    if e.status < 500 else "server_error", "code": e.status}})
+        except (BrokenPipeError, ConnectionResetError):
+            pass
+        finally:
+            with self._lock:
+                self.counters["latency_seconds_sum"] += time.perf_counter() - t0
+
+    def _send(self, h, status: int, payload: bytes, ctype: str) -> None:
+        h.send_response(status)
+        h.send_header("Content-Type", ctype)
+        h.send_header("Content-Length", str(len(payload)))
+        h.end_headers()
+        h.wfile.write(payload)
+
+    def _send_json(self, h, status: int, obj: Any) -> None:
+        self._send(h, status, json.dumps(obj).encode(), "application/json")
+
+    def _models(self) -> Dict[str, Any]:
+        now = int(time.time())
+        ids = [CONSENSUS_MODEL] + sorted(self.ensemble.backends)
+        return {"object": "list",
+                "data": [{"id": i, "object": "model", "created": now, "owned_by": "llm_consensus_amd"} for i in ids]}
+
+    def _metrics(self) -> str:
+        lines = []
+        with self._lock:
+            for k, v in self.counters.items():
+                lines.append(f"# TYPE consensus_http_{k} counter")
+                lines.append(f"consensus_http_{k} {v}")
+        lines.append(f"consensus_http_queue_depth {self.jobs.qsize()}")
+        for name, st in self.ensemble.stats().items():
+            for k, v in st.items():
+                if isinstance(v, (int, float)):
+                    lines.append(f'consensus_engine_{k}{{model="{name}"}} {v}')
+        return "\n".join(lines) + "\n"
+
+    # ---- request parsing
+    def _gen_params(self, body: Dict[str, Any]) -> GenParams:
+        s = self.ensemble.config.sampling
+        mt = body.get("max_completion_tokens", body.get("max_tokens"))
+        try:
+            return GenParams(
+                temperature=float(body.get("temperature", s.temperature)),
+                top_p=float(body.get("top_p", s.top_p)),
+                top_k=int(body.get("top_k", s.top_k)),
+                max_new_tokens=int(mt if mt is not None else s.max_new_tokens),
+                seed=int(body.get("seed", s.seed)),
+                n=int(body.get("n", 1)),
+            )
+        except (TypeError, ValueError) as e:
+            raise HTTPError(400, f"bad sampling parameter: {e}")
+
+    @staticmethod
+    def _chat_text(messages: List[Dict[str, Any]], consensus: bool) -> str:
+        if not isinstance(messages, list) or not messages:
+            raise HTTPError(400, "'messages' must be a non-empty list")
+
+        def content(m):
+            c = m.get("content", "")
+            if isinstance(c, list):  # content parts
+                c = "".join(p.get("text", "") for p in c if isinstance(p, dict))
+            return str(c)
+
+        if consensus:  # the strategy wraps the question in its own prompts
+            users = [m for m in messages if m.get("role") == "user"]
+            if not users:
+                raise HTTPError(400, "no user message")
+            return content(users[-1])
+        return "\n".join(f"{m.get('role', 'user')}: {content(m)}" for m in messages) + "\nassistant:"
+
+    def _completion(self, h, body: Dict[str, Any], chat: bool) -> None:
+        model = body.get("model") or CONSENSUS_MODEL
+        consensus = model == CONSENSUS_MODEL
+        if not consensus and model not in self.ensemble.backends:
+            raise HTTPError(404, f"unknown model {model!r}")
+        if chat:
+            text = self._chat_text(body.get("messages"), consensus)
+        else:
+            text = body.get("prompt")
+            if isinstance(text, list):
+                if len(text) != 1:
+                    raise HTTPError(400, "one prompt per request (send concurrent requests; they are batched)")
+                text = text[0]
+            if not isinstance(text, str) or not text:
+                raise HTTPError(400, "'prompt' must be a non-empty string")
+        params = self._gen_params(body)
+        job = self.submit(_Job("consensus" if consensus else "generate", model, text, params))
+        rid = ("chatcmpl-" if chat else "cmpl-") + uuid.uuid4().hex[:24]
+        created = int(time.time())
+        extra: Dict[str, Any] = {}
+        if consensus:
+            r = job.result
+            texts = [r.answer]
+            usage = {"prompt_tokens": 0, "completion_tokens": 0, "total_tokens": 0}
+            extra["consensus"] = {"strategy": r.strategy, "rounds": r.rounds, "member_calls": r.member_calls,
+                                  "unanimous": r.unanimous, "forced": r.forced, "agreement": r.agreement,
+                                  "proposer": r.proposer, "latency_s": r.latency_s, "votes": r.votes}
+        else:
+            g = job.result
+            texts = g.texts
+            ct = sum(len(t) for t in g.token_ids)
+            usage = {"prompt_tokens": g.prompt_tokens, "completion_tokens": ct,
+                     "total_tokens": g.prompt_tokens + ct,
+                     "prompt_tokens_details": {"cached_tokens": g.cached_tokens}}
+        if body.get("stream"):
+            return self._stream(h, rid, created, model, texts, chat, extra)
+        if chat:
+            choices = [{"index": i, "message": {"role": "assistant", "content": t}, "finish_reason": "stop"}
+                       for i, t in enumerate(texts)]
+            obj = "chat.completion"
+        else:
+            choices = [{"index": i, "text": t, "finish_reason": "stop", "logprobs": None} for i, t in enumerate(texts)]
+            obj = "text_completion"
+        self._send_json(h, 200, {"id": rid, "object": obj, "created": created, "model": model,
+                                 "choices": choices, "usage": usage, **extra})
+
+    def _stream(self, h, rid, created, model, texts, chat, extra) -> None:
+        """Server-sent events. Answers are produced whole (a consensus answer does not exist
+        until the vote is in), so each choice is one content chunk followed by a stop chunk."""
+        h.send_response(200)
+        h.send_header("Content-Type", "text/event-stream")
+        h.send_header("Cache-Control", "no-cache")
+        h.send_header("Connection", "close")
+        h.end_headers()
+        obj = "chat.completion.chunk" if chat else "text_completion"
+
+        def emit(choice, **more):
+            payload = {"id": rid, "object": obj, "created": created, "model": model, "choices": [choice], **more}
+            h.wfile.write(b"data: " + json.dumps(payload).encode() + b"\n\n")
+
+        for i, t in enumerate(texts):
+            if chat:
+                emit({"index": i, "delta": {"role": "assistant", "content": t}, "finish_reason": None})
+                emit({"index": i, "delta": {}, "finish_reason": "stop"}, **extra)
+            else:
+                emit({"index": i, "text": t, "finish_reason": "stop"}, **extra)
+        h.wfile.write(b"data: [DONE]\n\n")
+        h.wfile.flush()
+        h.close_connection = True
+
+    def _embeddings(self, h, body: Dict[str, Any]) -> None:
+        model = body.get("model")
+        if not model or model == CONSENSUS_MODEL:
+            emb = [m for m in self.ensemble.members if m.role == "embedder"] or self.ensemble.members
+            model = next(k for k, b in self.ensemble.backends.items() if b is emb[0].backend)
+        if model not in self.ensemble.backends:
+            raise HTTPError(404, f"unknown model {model!r}")
+        inp = body.get("input")
+        inputs = [inp] if isinstance(inp, str) else inp
+        if not isinstance(inputs, list) or not inputs or not all(isinstance(x, str) and x for x in inputs):
+            raise HTTPError(400, "'input' must be a non-empty string or list of strings")
+        jobs = [_Job("embed", model, x) for x in inputs]
+        for j in jobs[:-1]:
+            self.jobs.put(j)
+        self.submit(jobs[-1])
+        data = []
+        for i, j in enumerate(jobs):
+            if not j.done.wait(self.request_timeout_s):
+                raise HTTPError(504, "request timed out in the engine queue")
+            if j.error:
+                raise HTTPError(500, j.error)
+            data.append({"object": "embedding", "index": i, "embedding": [float(x) for x in j.result]})
+        self._send_json(h, 200, {"object": "list", "data": data, "model": model,
+                                 "usage": {"prompt_tokens": 0, "total_tokens": 0}})
+
+
+def main(argv: Optional[list] = None) -> int:
+    import argparse
+
+    from ..app import build_ensemble
+    from ..config import load_config
+
+    ap = argparse.ArgumentParser(prog="llm-consensus-serve", description="OpenAI-compatible consensus endpoint")
+    ap.add_argument("--config")
+    ap.add_argument("--host", default="127.0.0.1")
+    ap.add_argument("--port", type=int, default=8000)
+    ap.add_argument("--max-batch", type=int, default=64)
+    ap.add_argument("--batch-window-ms", type=float, default=5.0)
+    args = ap.parse_args(argv)
+    ens = build_ensemble(load_config(args.config))
+    ConsensusServer(ens, args.host, args.port, args.max_batch, args.batch_window_ms).serve_forever()
+    return 0
+
+
+if __name__ == "__main__":
+    raise SystemExit(main())

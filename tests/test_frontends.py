@@ -1,0 +1,213 @@
+"""Front ends on CPU: config files -> ensemble, the REPL, the OpenAI-compatible endpoint
+and the placement planner. The REPL contract follows /root/reference/src/main.rs:428-471
+(prompt text, ``exit``, reset between questions)."""
+import io
+import json
+import threading
+import urllib.error
+import urllib.request
+from pathlib import Path
+
+import pytest
+import torch
+
+from llm_consensus_amd import cli
+from llm_consensus_amd.app import build_ensemble
+from llm_consensus_amd.config import ConsensusConfig, load_config
+from llm_consensus_amd.consensus.backend import ScriptedBackend
+from llm_consensus_amd.parallel.placement import assignment_for_rank, plan_for_config
+from llm_consensus_amd.serve.server import ConsensusServer
+
+CONFIGS = Path(__file__).resolve().parent.parent / "configs"
+CPU = torch.device("cpu")
+
+
+@pytest.fixture(scope="module")
+def tiny_ensemble():
+    return build_ensemble(load_config(str(CONFIGS / "plumbing_tiny.toml")), CPU)
+
+
+def test_every_example_config_loads():
+    for f in sorted(CONFIGS.glob("*.toml")):
+        cfg = load_config(str(f))
+        assert cfg.members, f.name
+        for m in cfg.members:
+            assert m.model in cfg.models
+
+
+def test_default_config_is_reference_topology():
+    cfg = ConsensusConfig()
+    assert [m.name for m in cfg.members] == ["High Society", "The Technician", "Art Boy", "Programming Nerd"]
+    assert cfg.strategy == "reference_protocol" and cfg.max_rounds == 5
+    assert len({m.model for m in cfg.members}) == 1
+
+
+def test_plumbing_majority_vote_three_tiny_models(tiny_ensemble):
+    res = tiny_ensemble.ask_many(["Which letter comes first? A) a B) b C) c D) d", "2+2? A) 3 B) 4 C) 5 D) 6"])
+    assert len(res) == 2
+    for r in res:
+        assert r.strategy == "majority_vote" and r.answer in list("ABCD")
+        assert len(r.votes) == 3 and r.member_calls == 3
+        counts = [sum(v["class"] == c for v in r.votes) for c in range(4)]
+        assert counts["ABCD".index(r.answer)] == max(counts)
+    # deterministic: the same question gives the same votes again
+    again = tiny_ensemble.ask(res[0].question)
+    assert [v["class"] for v in again.votes] == [v["class"] for v in res[0].votes]
+
+
+def scripted_reference_ensemble(**kw):
+    be = ScriptedBackend({"propose": ["first draft"], "evaluate": ["NeedsRefinement\nmeh"] + ["Good\nfine"] * 16,
+                          "refine": ["second draft"]}, **kw)
+    return build_ensemble(ConsensusConfig(), CPU, backends={"default": be})
+
+
+def test_repl_prompt_exit_and_answer():
+    ens = scripted_reference_ensemble()
+    out = io.StringIO()
+    n = cli.repl(ens, io.StringIO("What is art?\n\nexit\nnever read\n"), out)
+    text = out.getvalue()
+    assert n == 1
+    assert text.count(cli.PROMPT) == 3          # question, blank line, exit
+    assert "second draft" in text or "first draft" in text
+    assert "never read" not in text
+
+
+def test_repl_eof_ends_loop_and_json_mode():
+    ens = scripted_reference_ensemble()
+    out = io.StringIO()
+    assert cli.repl(ens, io.StringIO("q one\n"), out, as_json=True) == 1
+    rec = json.loads(out.getvalue().split(cli.PROMPT)[1].strip().splitlines()[0])
+    assert rec["question"] == "q one" and rec["strategy"] == "reference_protocol" and rec["rounds"] >= 1
+
+
+def test_repl_survives_a_failing_session():
+    class Boom:
+        def ask(self, q):
+            raise RuntimeError("engine fell over")
+
+    out = io.StringIO()
+    assert cli.repl(Boom(), io.StringIO("q\nexit\n"), out) == 0
+    assert "System error: engine fell over" in out.getvalue()
+
+
+def test_cli_questions_file(tmp_path, capsys):
+    qf = tmp_path / "q.txt"
+    qf.write_text("one? A) x B) y C) z D) w\n\nsecond? A) x B) y C) z D) w\n")
+    rc = cli.main(["--config", str(CONFIGS / "plumbing_tiny.toml"), "--questions", str(qf), "--json", "--device", "cpu"])
+    assert rc == 0
+    lines = [json.loads(x) for x in capsys.readouterr().out.strip().splitlines()]
+    assert len(lines) == 2 and all(x["answer"] in "ABCD" for x in lines)
+
+
+# ---------------------------------------------------------------- HTTP endpoint
+def _post(port, path, body, timeout=120):
+    req = urllib.request.Request(f"http://127.0.0.1:{port}{path}", json.dumps(body).encode(),
+                                 {"Content-Type": "application/json"})
+    with urllib.request.urlopen(req, timeout=timeout) as r:
+        return r.status, r.read()
+
+
+def _get(port, path):
+    with urllib.request.urlopen(f"http://127.0.0.1:{port}{path}", timeout=30) as r:
+        return r.status, r.read()
+
+
+@pytest.fixture(scope="module")
+def server(tiny_ensemble):
+    srv = ConsensusServer(tiny_ensemble, port=0, max_batch=16, batch_window_ms=30).start()
+    yield srv
+    srv.shutdown()
+
+
+def test_http_health_models_metrics(server):
+    st, body = _get(server.port, "/health")
+    assert st == 200 and json.loads(body)["status"] == "ok"
+    ids = [m["id"] for m in json.loads(_get(server.port, "/v1/models")[1])["data"]]
+    assert ids == ["consensus", "m0", "m1", "m2"]
+    assert b"consensus_http_requests_total" in _get(server.port, "/metrics")[1]
+
+
+def test_http_chat_consensus_matches_direct_call(server, tiny_ensemble):
+    q = "Pick one. A) red B) green C) blue D) grey"
+    st, body = _post(server.port, "/v1/chat/completions",
+                     {"model": "consensus", "messages": [{"role": "system", "content": "be brief"},
+                                                         {"role": "user", "content": q}]})
+    obj = json.loads(body)
+    assert st == 200 and obj["object"] == "chat.completion"
+    direct = tiny_ensemble.ask(q)
+    assert obj["choices"][0]["message"]["content"] == direct.answer
+    assert [v["class"] for v in obj["consensus"]["votes"]] == [v["class"] for v in direct.votes]
+
+
+def test_http_concurrent_requests_are_batched(server):
+    before = dict(server.counters)
+    results = [None] * 8
+
+    def call(i):
+        results[i] = json.loads(_post(server.port, "/v1/chat/completions",
+                                      {"messages": [{"role": "user", "content": f"Q{i}? A) a B) b C) c D) d"}]})[1])
+
+    ts = [threading.Thread(target=call, args=(i,)) for i in range(8)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert all(r and r["choices"][0]["message"]["content"] in list("ABCD") for r in results)
+    batches = server.counters["batches_total"] - before["batches_total"]
+    assert batches < 8, "concurrent callers should share engine batches"
+
+
+def test_http_member_model_completion_and_stream(server):
+    st, body = _post(server.port, "/v1/completions", {"model": "m1", "prompt": "hello", "max_tokens": 5, "n": 2,
+                                                      "temperature": 0.9, "seed": 7})
+    obj = json.loads(body)
+    assert st == 200 and len(obj["choices"]) == 2 and obj["usage"]["completion_tokens"] == 10
+    st, raw = _post(server.port, "/v1/chat/completions",
+                    {"model": "m0", "stream": True, "max_tokens": 4, "messages": [{"role": "user", "content": "hi"}]})
+    events = [l[6:] for l in raw.decode().splitlines() if l.startswith("data: ")]
+    assert events[-1] == "[DONE]"
+    assert json.loads(events[0])["choices"][0]["delta"]["role"] == "assistant"
+    assert json.loads(events[1])["choices"][0]["finish_reason"] == "stop"
+
+
+def test_http_embeddings(server):
+    st, body = _post(server.port, "/v1/embeddings", {"model": "m0", "input": ["alpha", "beta"]})
+    data = json.loads(body)["data"]
+    assert st == 200 and len(data) == 2
+    v = torch.tensor(data[0]["embedding"])
+    assert v.numel() == 128 and abs(float(v.norm()) - 1.0) < 1e-2
+
+
+def test_http_errors(server):
+    for path, body, code in [("/v1/chat/completions", {"model": "nope", "messages": [{"role": "user", "content": "x"}]}, 404),
+                             ("/v1/chat/completions", {"messages": []}, 400),
+                             ("/v1/completions", {"prompt": ""}, 400),
+                             ("/v1/nothing", {}, 404)]:
+        with pytest.raises(urllib.error.HTTPError) as ei:
+            _post(server.port, path, body)
+        assert ei.value.code == code
+        assert "error" in json.loads(ei.value.read())
+
+
+# ---------------------------------------------------------------- placement
+def test_placement_three_small_models_pack_to_one_gpu_and_replicate():
+    cfg = load_config(str(CONFIGS / "ensemble_3x8b.toml"))
+    plan = plan_for_config(cfg, 8)
+    assert plan.feasible and plan.gpus_per_replica == 1 and len(plan.replicas) == 8
+    a = assignment_for_rank(plan, cfg, 5)
+    assert a.replica == 5 and a.num_replicas == 8 and sorted(a.models) == ["llama", "mistral", "qwen"]
+
+
+def test_placement_70b_judge_spread():
+    cfg = load_config(str(CONFIGS / "judge_70b_tp4.toml"))
+    plan = plan_for_config(cfg, 8)
+    assert plan.feasible
+    rep = plan.replicas[0]
+    judge = next(m for m in rep.members if m.name == "judge")
+    assert len(judge.devices) == 4
+    for r in judge.devices:
+        assert assignment_for_rank(plan, cfg, r).models["judge"] == list(judge.devices)
+
+
+def test_placement_infeasible_reports_error():
+    cfg = load_config(str(CONFIGS / "judge_70b_tp4.toml"))
+    plan = plan_for_config(cfg, 2)
+    assert not plan.feasible and plan.error
