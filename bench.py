@@ -95,6 +95,7 @@ def main() -> None:
     from llm_consensus_amd.models.config import get_preset
     from llm_consensus_amd.models.transformer import TransformerModel
     from llm_consensus_amd.parallel.comm import make_comm
+    from llm_consensus_amd.parallel.replica import gather_winners
     from llm_consensus_amd.utils.tokenizer import ByteLevelTokenizer
 
     comm = make_comm(dist, dev)
@@ -123,9 +124,8 @@ def main() -> None:
     rng = np.random.default_rng(1000 + rank)
 
     def gather_answers(results):
-        """X4: cross-GPU gather of the per-question winners (class ids) to every rank."""
-        w = torch.tensor([("ABCD".find(r.answer) if r.answer else -1) for r in results], dtype=torch.int32, device=dev)
-        return comm.all_gather_rows(w)
+        """Cross-GPU gather of the per-question winners (class ids) to every rank."""
+        return gather_winners(comm, results, "ABCD", dev)
 
     def run_phase(strategy, n_q, steps, warmup):
         lat = []

@@ -58,10 +58,10 @@ class SafetensorsIndex:
 
 
 def load_model(path: str, device, tp_rank: int = 0, tp_size: int = 1, comm=None,
-               cfg: Optional[ModelConfig] = None) -> TransformerModel:
+               cfg: Optional[ModelConfig] = None, ep_size: int = 1, ep_mode: str = "allreduce") -> TransformerModel:
     cfg = cfg or from_hf_config(path)
     index = SafetensorsIndex(path)
-    model = TransformerModel(cfg, device, tp_rank, tp_size, comm)
+    model = TransformerModel(cfg, device, tp_rank, tp_size, comm, ep_size, ep_mode)
     model.set_weights_from_hf(index.get)
     return model
 
@@ -103,10 +103,11 @@ def write_random_checkpoint(cfg: ModelConfig, path: str, seed: int = 0, std: flo
     return out
 
 
-def build_model(spec, device, tp_rank: int = 0, tp_size: int = 1, comm=None) -> TransformerModel:
+def build_model(spec, device, tp_rank: int = 0, tp_size: int = 1, comm=None, ep_size: int = 1,
+                ep_mode: str = "allreduce") -> TransformerModel:
     """From a config.ModelSpec: a checkpoint path wins; otherwise random-init of a preset."""
     if getattr(spec, "path", None):
-        return load_model(spec.path, device, tp_rank, tp_size, comm)
+        return load_model(spec.path, device, tp_rank, tp_size, comm, ep_size=ep_size, ep_mode=ep_mode)
     cfg = get_preset(spec.preset or "tiny-llama")
     return TransformerModel.random_init(cfg, device, seed=getattr(spec, "seed", 0), tp_rank=tp_rank,
-                                        tp_size=tp_size, comm=comm)
+                                        tp_size=tp_size, comm=comm, ep_size=ep_size, ep_mode=ep_mode)

@@ -12,6 +12,7 @@ all-reduces and the logits all-gather go through ``parallel.comm.Comm`` (RCCL).
 """
 from __future__ import annotations
 
+import zlib
 from dataclasses import dataclass, field
 from typing import Dict, List, Optional, Tuple
 
@@ -19,6 +20,7 @@ import torch
 
 from .. import ops
 from ..ops import reference as ref
+from ..parallel.ep import expert_range, moe_ffn_ep
 from .config import ModelConfig
 
 
@@ -80,12 +82,22 @@ class KVCache:
 
 
 class TransformerModel:
-    def __init__(self, cfg: ModelConfig, device, tp_rank: int = 0, tp_size: int = 1, comm=None) -> None:
+    def __init__(self, cfg: ModelConfig, device, tp_rank: int = 0, tp_size: int = 1, comm=None,
+                 ep_size: int = 1, ep_mode: str = "allreduce") -> None:
+        """``comm`` is the communicator of this model's parallel group. Tensor parallelism
+        (``tp_size`` = group size) shards heads, MLP columns and vocabulary; expert
+        parallelism (``ep_size`` = group size, ``tp_size`` 1) keeps the dense parts replicated
+        and shards Mixtral's experts (see parallel/ep.py)."""
         cfg.validate()
         if cfg.num_kv_heads % tp_size or cfg.intermediate_size % (16 * tp_size):
             raise ValueError(f"{cfg.name}: tp={tp_size} does not divide kv heads / d_ff")
+        if ep_size > 1 and (tp_size > 1 or not cfg.is_moe):
+            raise ValueError(f"{cfg.name}: expert parallelism needs an MoE model and tp=1")
         self.cfg, self.device = cfg, torch.device(device)
         self.tp_rank, self.tp_size, self.comm = tp_rank, tp_size, comm
+        self.ep_size, self.ep_mode = ep_size, ep_mode
+        self.ep_rank = comm.rank if (ep_size > 1 and comm is not None) else 0
+        self.expert_lo, self.expert_hi = expert_range(cfg.num_experts, self.ep_rank, ep_size) if cfg.is_moe else (0, 0)
         self.hq = cfg.num_heads // tp_size
         self.hkv = cfg.num_kv_heads // tp_size
         self.dff = cfg.intermediate_size // tp_size
@@ -137,9 +149,9 @@ class TransformerModel:
                 lw.router = bf(get(m + "gate.weight")).to(dev).contiguous()
                 gu = torch.stack([ops.interleave_gate_up(bf(get(f"{m}experts.{e}.w1.weight")[sl]),
                                                          bf(get(f"{m}experts.{e}.w3.weight")[sl]))
-                                  for e in range(c.num_experts)])
+                                  for e in range(self.expert_lo, self.expert_hi)])
                 dn = torch.stack([bf(get(f"{m}experts.{e}.w2.weight")[:, sl]).contiguous()
-                                  for e in range(c.num_experts)])
+                                  for e in range(self.expert_lo, self.expert_hi)])
                 lw.experts_gate_up = ops.ExpertWeights.from_dense(gu, dev, swiglu=True)
                 lw.experts_down = ops.ExpertWeights.from_dense(dn, dev)
             else:
@@ -151,14 +163,13 @@ class TransformerModel:
 
     @classmethod
     def random_init(cls, cfg: ModelConfig, device, seed: int = 0, tp_rank: int = 0, tp_size: int = 1, comm=None,
-                    std: float = 0.02) -> "TransformerModel":
+                    std: float = 0.02, ep_size: int = 1, ep_mode: str = "allreduce") -> "TransformerModel":
         """Random weights of the configured architecture generated directly on ``device``
         (no checkpoint files; used by benchmarks and smoke tests). Every rank draws the
         full tensors from the same seed and keeps its shard, so TP ranks are consistent."""
-        m = cls(cfg, device, tp_rank, tp_size, comm)
+        m = cls(cfg, device, tp_rank, tp_size, comm, ep_size, ep_mode)
         dev = m.device
         gen = torch.Generator(device=dev)
-        gen.manual_seed(seed)
         cache: Dict[str, torch.Tensor] = {}
 
         def get(name: str) -> torch.Tensor:
@@ -167,6 +178,9 @@ class TransformerModel:
                 return torch.ones(shape, dtype=torch.bfloat16, device=dev)
             if name == "model.embed_tokens.weight" and name in cache:
                 return cache[name]
+            # one stream per tensor name: a rank that skips tensors (non-resident experts)
+            # still draws the same values for the ones it keeps
+            gen.manual_seed((seed * 1000003 + zlib.crc32(name.encode())) & 0x7FFFFFFFFFFFFFFF)
             t = (torch.randn(shape, generator=gen, device=dev, dtype=torch.float32) * std).to(torch.bfloat16)
             if name == "model.embed_tokens.weight":
                 cache[name] = t
@@ -212,17 +226,23 @@ class TransformerModel:
                                     meta.max_group_rows, meta.prefix_splits)
             o = self._all_reduce(ops.linear(a, L.o))
             x2 = ops.rmsnorm(h, L.ln2, c.rms_eps, o)
-            if c.is_moe:
-                delta = ops.moe_ffn(x2, L.router, L.experts_gate_up, L.experts_down, c.experts_per_tok)
+            if c.is_moe and self.ep_size > 1:
+                delta = moe_ffn_ep(x2, L.router, L.experts_gate_up, L.experts_down, c.experts_per_tok, self.comm,
+                                   self.expert_lo, self.ep_mode)
+            elif c.is_moe:
+                delta = self._all_reduce(ops.moe_ffn(x2, L.router, L.experts_gate_up, L.experts_down,
+                                                     c.experts_per_tok))
             else:
-                delta = ops.linear(ops.linear(x2, L.gate_up), L.down)
-            delta = self._all_reduce(delta)
+                delta = self._all_reduce(ops.linear(ops.linear(x2, L.gate_up), L.down))
         return ops.rmsnorm(h, self.final_norm, c.rms_eps, delta)
 
     def logits(self, hidden_rows: torch.Tensor) -> torch.Tensor:
         """fp32 logits [R, V] for the given hidden rows (vocab-parallel + all-gather under TP)."""
         lg = ops.linear(hidden_rows, self.lm_head, out_f32=True)
         if self.tp_size > 1:
+            vshard = (self.cfg.vocab_size + self.tp_size - 1) // self.tp_size
+            if lg.shape[1] < vshard:  # ragged last shard: equal-sized parts for the all-gather
+                lg = torch.nn.functional.pad(lg, (0, vshard - lg.shape[1]), value=float("-inf"))
             lg = self.comm.all_gather_cols(lg, self.cfg.vocab_size)
         return lg
 

@@ -369,41 +369,67 @@ class ExpertWeights:
         return self.data.numel() * self.data.element_size()
 
 
-def moe_ffn(x: torch.Tensor, Wr: torch.Tensor, w_gate_up: ExpertWeights, w_down: ExpertWeights, topk: int):
-    """Mixtral block-sparse FFN: route, run the selected experts' SwiGLU MLP, combine."""
-    T, d = x.shape
-    E = Wr.shape[0]
+def moe_route(x: torch.Tensor, Wr: torch.Tensor, topk: int):
+    """Top-k routing with softmax over the selected logits: (ids int32 [T,k], weights fp32 [T,k])."""
     if not x.is_cuda:
         ids, wts, _ = ref.moe_router(x, Wr, topk)
+        return ids.to(torch.int32), wts
+    h = _hip()
+    T, d = x.shape
+    ids = torch.empty(T, topk, dtype=torch.int32, device=x.device)
+    wts = torch.empty(T, topk, dtype=torch.float32, device=x.device)
+    h.call("lc_moe_router", x.data_ptr(), Wr.data_ptr(), T, d, Wr.shape[0], topk, ids.data_ptr(), wts.data_ptr(), None)
+    return ids, wts
+
+
+def _expert_mlp_cpu(xe: torch.Tensor, w_gate_up: "ExpertWeights", w_down: "ExpertWeights", e: int) -> torch.Tensor:
+    gu = ref.linear(xe, w_gate_up.data[e], None, torch.float32)
+    gu = gu.view(-1, w_gate_up.n // 32, 2, 16)
+    act = (torch.nn.functional.silu(gu[:, :, 0]) * gu[:, :, 1]).reshape(xe.shape[0], -1).to(xe.dtype)
+    return ref.linear(act, w_down.data[e], None, xe.dtype).float()
+
+
+def moe_experts(x: torch.Tensor, ids: torch.Tensor, wts: torch.Tensor, w_gate_up: "ExpertWeights",
+                w_down: "ExpertWeights", expert_lo: int = 0, n_experts: Optional[int] = None) -> torch.Tensor:
+    """sum_k wts[t,k] * MLP_{ids[t,k]}(x[t]) over the experts held in ``w_*`` (global ids
+    [expert_lo, expert_lo + E_local)); (token, k) pairs routed elsewhere contribute zero, so
+    expert-parallel ranks can sum their results. ``n_experts`` is the global expert count."""
+    T, d = x.shape
+    topk = ids.shape[1]
+    E_local = w_gate_up.data.shape[0]
+    E = n_experts or (expert_lo + E_local)
+    if not x.is_cuda:
         out = torch.zeros(T, d, dtype=torch.float32)
-        for e in range(E):
-            tok, slot = torch.nonzero(ids == e, as_tuple=True)
-            if tok.numel() == 0:
-                continue
-            xe = x[tok]
-            gu = ref.linear(xe, w_gate_up.data[e], None, torch.float32)
-            gu = gu.view(-1, w_gate_up.n // 32, 2, 16)
-            act = (torch.nn.functional.silu(gu[:, :, 0]) * gu[:, :, 1]).reshape(tok.numel(), -1).to(x.dtype)
-            ye = ref.linear(act, w_down.data[e], None, x.dtype).float()
-            out.index_add_(0, tok, ye * wts[tok, slot][:, None])
+        for e in range(E_local):
+            tok, slot = torch.nonzero(ids == expert_lo + e, as_tuple=True)
+            if tok.numel():
+                out.index_add_(0, tok, _expert_mlp_cpu(x[tok], w_gate_up, w_down, e) * wts[tok, slot][:, None])
         return out.to(x.dtype)
     h = _hip()
     dev = x.device
-    ids = torch.empty(T, topk, dtype=torch.int32, device=dev)
-    wts = torch.empty(T, topk, dtype=torch.float32, device=dev)
-    h.call("lc_moe_router", x.data_ptr(), Wr.data_ptr(), T, d, E, topk, ids.data_ptr(), wts.data_ptr(), None)
     offsets = torch.empty(E + 1, dtype=torch.int32, device=dev)
     sorted_src = torch.empty(T * topk, dtype=torch.int32, device=dev)
     slot_of = torch.empty(T * topk, dtype=torch.int32, device=dev)
     h.call("lc_moe_permute", ids.data_ptr(), T, topk, E, offsets.data_ptr(), sorted_src.data_ptr(), slot_of.data_ptr())
+    off_local = offsets.data_ptr() + 4 * expert_lo          # the kernels index rows by absolute offsets
+    partial = E_local != E
     dff = w_gate_up.n // 2
     act = torch.empty(T * topk, dff, dtype=x.dtype, device=dev)
     h.call("lc_gemm_grouped", w_gate_up.data.data_ptr(), w_gate_up.data[0].numel(), x.data_ptr(),
-           sorted_src.data_ptr(), offsets.data_ptr(), E, act.data_ptr(), T * topk, w_gate_up.n, w_gate_up.k,
+           sorted_src.data_ptr(), off_local, E_local, act.data_ptr(), T * topk, w_gate_up.n, w_gate_up.k,
            w_gate_up.n_pad, dff, EPI_SWIGLU)
-    y = torch.empty(T * topk, d, dtype=x.dtype, device=dev)
+    y = (torch.zeros if partial else torch.empty)(T * topk, d, dtype=x.dtype, device=dev)
     h.call("lc_gemm_grouped", w_down.data.data_ptr(), w_down.data[0].numel(), act.data_ptr(), None,
-           offsets.data_ptr(), E, y.data_ptr(), T * topk, w_down.n, w_down.k, w_down.n_pad, d, EPI_BF16)
+           off_local, E_local, y.data_ptr(), T * topk, w_down.n, w_down.k, w_down.n_pad, d, EPI_BF16)
     out = torch.empty(T, d, dtype=x.dtype, device=dev)
     h.call("lc_moe_combine", y.data_ptr(), slot_of.data_ptr(), wts.data_ptr(), out.data_ptr(), T, d, topk)
     return out
+
+
+def moe_ffn(x: torch.Tensor, Wr: torch.Tensor, w_gate_up: ExpertWeights, w_down: ExpertWeights, topk: int,
+            expert_lo: int = 0) -> torch.Tensor:
+    """Mixtral block-sparse FFN: route, run the selected experts' SwiGLU MLP, combine. With a
+    subset of the experts resident (``expert_lo``, stacked weights shorter than the router)
+    the result is this rank's partial sum."""
+    ids, wts = moe_route(x, Wr, topk)
+    return moe_experts(x, ids, wts, w_gate_up, w_down, expert_lo, Wr.shape[0])
