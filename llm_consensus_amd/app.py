@@ -58,7 +58,11 @@ def model_config_of(spec: ModelSpec):
 
 
 def build_backend(spec: ModelSpec, device: torch.device, comm=None, tp_rank: int = 0) -> EngineBackend:
-    model = build_model(spec, device, tp_rank=tp_rank, tp_size=spec.tp, comm=comm)
+    """One engine for ``spec``. With tp/ep > 1, ``comm`` is the model's group and this
+    process holds shard ``tp_rank`` (= comm.rank); a single process ignores tp/ep."""
+    grouped = comm is not None and comm.world > 1
+    model = build_model(spec, device, tp_rank=tp_rank, tp_size=spec.tp if grouped else 1, comm=comm,
+                        ep_size=spec.ep if grouped else 1, ep_mode=spec.ep_mode)
     max_len = min(model.cfg.max_position, 4096)
     eng = Engine(model, block_size=spec.kv_block_size if device.type == "cuda" else 16,
                  max_batch_seqs=spec.max_batch_seqs, max_prefill_tokens=spec.max_prefill_tokens,
@@ -83,16 +87,20 @@ def build_ensemble(cfg: ConsensusConfig, device: Optional[torch.device] = None,
     for name in used_models:
         if name not in backends:
             backends[name] = build_backend(cfg.models[name], device)
+    members = make_members(cfg, backends)
+    strategy = make_strategy(cfg, members, device)
+    return Ensemble(cfg, members, backends, strategy, device)
+
+
+def make_members(cfg: ConsensusConfig, backends: Dict[str, Backend]) -> List[Member]:
     gp = GenParams(temperature=cfg.sampling.temperature, top_p=cfg.sampling.top_p, top_k=cfg.sampling.top_k,
                    max_new_tokens=cfg.sampling.max_new_tokens, seed=cfg.sampling.seed)
     templates = cfg.templates()
-    members = [
+    return [
         Member(core.Persona(m.name, m.domain, m.tuning), backends[m.model], templates, gp, cfg.parse_mode_enum(),
                cfg.decision_mode, m.role, m.weight)
         for m in cfg.members
     ]
-    strategy = make_strategy(cfg, members, device)
-    return Ensemble(cfg, members, backends, strategy, device)
 
 
 def make_strategy(cfg: ConsensusConfig, members: List[Member], device):

@@ -93,6 +93,9 @@ def main(argv: Optional[list] = None) -> int:
     ap.add_argument("--json", action="store_true", help="print one JSON record per answer")
     ap.add_argument("--strategy", help="override the configured strategy")
     ap.add_argument("--device", help="cuda[:N] or cpu (default: GPU when present)")
+    ap.add_argument("--distributed", action="store_true",
+                    help="one process per GPU under torch.distributed.run: members are placed over the "
+                         "node's GPUs by the planner; rank 0 owns the terminal")
     args = ap.parse_args(argv)
 
     cfg: ConsensusConfig = load_config(args.config)
@@ -104,12 +107,25 @@ def main(argv: Optional[list] = None) -> int:
     from .app import build_ensemble
 
     device = torch.device(args.device) if args.device else None
-    ensemble = build_ensemble(cfg, device)
+    leader = None
+    if args.distributed:
+        from .parallel.ensemble_parallel import DistributedEnsemble, LeaderEnsemble, follow, init_distributed
+
+        comm, device = init_distributed(device.type if device else None)
+        dist_ens = DistributedEnsemble(cfg, comm, device)
+        if comm.rank != 0:
+            follow(dist_ens)
+            return 0
+        ensemble = leader = LeaderEnsemble(dist_ens)
+    else:
+        ensemble = build_ensemble(cfg, device)
     if args.questions:
         with open(args.questions) as f:
             answer_file(ensemble, f, as_json=args.json)
     else:
         repl(ensemble, as_json=args.json)
+    if leader is not None:
+        leader.close()
     return 0
 
 

@@ -49,6 +49,7 @@ class ModelSpec:
     dtype: str = "bf16"
     tp: int = 1
     ep: int = 1
+    ep_mode: str = "allreduce"        # allreduce | a2a (see parallel/ep.py)
     devices: Optional[List[int]] = None
     kv_block_size: int = 64
     kv_fraction: float = 0.6          # share of free HBM given to the KV pool

@@ -99,8 +99,26 @@ class Backend:
         """Drive the backend until every submitted handle is done."""
         raise NotImplementedError
 
+    def run_local(self) -> None:
+        """Compute phase of run(): everything that needs no other backend's ranks."""
+        self.run()
+
+    def sync(self) -> None:
+        """Exchange phase of run(): publish results to ranks that do not host this backend
+        (a no-op for backends that live entirely in this process)."""
+
     def stats(self) -> Dict[str, float]:
         return {}
+
+
+def run_backends(backends: Sequence["Backend"]) -> None:
+    """Completes the submitted requests of several backends. All compute phases are started
+    before any exchange phase, so backends hosted on different GPUs work concurrently and a
+    rank that hosts none of them waits only once."""
+    for b in backends:
+        b.run_local()
+    for b in backends:
+        b.sync()
 
 
 class CallableBackend(Backend):

@@ -23,7 +23,8 @@ from typing import Dict, List, Optional, Sequence
 
 from .._native import core
 from ..utils.log import get_logger
-from .backend import BackendError, Handle
+from ..utils.trace import span
+from .backend import BackendError, Handle, run_backends
 from .members import Member, distinct_backends
 
 log = get_logger("consensus.coordinator")
@@ -103,6 +104,7 @@ class Coordinator:
         backends = distinct_backends(self.members)
 
         pending = list(live)
+        wave = 0
         while pending:
             # ---- submit ----
             for L in pending:
@@ -117,8 +119,10 @@ class Coordinator:
                     log.debug("Asking %s to refine the answer.", self.members[a.member].name)
                     L.handles = [self.members[a.member].submit_refine(s.question, s.answer(), s.refiner_context())]
             # ---- run ----
-            for b in backends:
-                b.run()
+            wave += 1
+            with span(f"wave{wave}", "protocol", sessions=len(pending),
+                      calls=sum(len(L.handles) for L in pending)):
+                run_backends(backends)
             # ---- collect ----
             nxt: List[_Live] = []
             for L in pending:

@@ -28,6 +28,7 @@ import numpy as np
 
 from .._native import core
 from ..utils.log import get_logger
+from ..utils.trace import span
 from . import reducers
 from .backend import BackendError, GenParams
 from .members import Member, distinct_backends
@@ -36,9 +37,13 @@ from .protocol import ConsensusResult
 log = get_logger("consensus.strategy")
 
 
-def _run_all(members: Sequence[Member]) -> None:
-    for b in distinct_backends(list(members)):
-        b.run()
+def _run_all(members: Sequence[Member], phase: str = "generate") -> None:
+    backends = distinct_backends(list(members))
+    for b in backends:
+        with span(f"{phase}:{b.name}", "strategy"):
+            b.run_local()
+    for b in backends:
+        b.sync()
 
 
 def _classify(text: str, decision_lp: Optional[List[float]], choices: str) -> int:
@@ -88,7 +93,8 @@ class MajorityVote:
                 texts[r][i] = res.texts[0]
                 dec = res.decision_logprobs[0] if res.decision_logprobs else None
                 votes[r, i] = _classify(res.texts[0], dec, self.choices)
-        red = reducers.majority_vote_batch(votes, len(self.choices), self.tie_break, device=self.device)
+        with span("reduce", "strategy"):
+            red = reducers.majority_vote_batch(votes, len(self.choices), self.tie_break, device=self.device)
         dt = time.perf_counter() - t0
         out = []
         for r, q in enumerate(questions):
@@ -165,7 +171,8 @@ class SelfConsistency:
                     dec = res.decision_logprobs[c] if res.decision_logprobs else None
                     votes[r, c] = _classify(text, dec, self.choices)
         ncls = max(len(self.choices), max((len(l) for l in labels), default=0), 1)
-        red = reducers.majority_vote_batch(votes, ncls, self.tie_break, device=self.device)
+        with span("reduce", "strategy"):
+            red = reducers.majority_vote_batch(votes, ncls, self.tie_break, device=self.device)
         out = []
         for r, q in enumerate(questions):
             w = int(red.winner[r])
@@ -223,7 +230,7 @@ class JudgeLogprob:
             cands.append(row)
         score_h = [[[j.backend.submit_score(self.judge_prompt(q, c), self.JUDGE_TARGETS) for j in self.judges]
                     for c in cands[r]] for r, q in enumerate(questions)]
-        _run_all(self.judges)
+        _run_all(self.judges, "judge")
         C, J = len(self.proposers), len(self.judges)
         scores = np.full((len(questions), C, J), -1e30, dtype=np.float32)
         for r in range(len(questions)):
@@ -237,7 +244,8 @@ class JudgeLogprob:
                     except BackendError as e:
                         log.error("%s failed to score: %s", self.judges[j].name, e)
                         scores[r, c, j] = 0.0
-        red = reducers.judge_reduce_batch(scores, device=self.device)
+        with span("reduce", "strategy"):
+            red = reducers.judge_reduce_batch(scores, device=self.device)
         out = []
         for r, q in enumerate(questions):
             w = int(red.winner[r])
@@ -294,7 +302,7 @@ class EmbeddingMedoid:
             cands.append(row)
             owners.append(own)
         emb_h = [[self.embedder.backend.submit_embed(c) for c in cands[r]] for r in range(len(questions))]
-        _run_all([self.embedder])
+        _run_all([self.embedder], "embed")
         out = []
         for r, q in enumerate(questions):
             if not cands[r]:

@@ -20,6 +20,7 @@ from .. import ops
 from .._native import core
 from ..models.transformer import AttnMeta, KVCache, TransformerModel
 from ..utils.log import get_logger
+from ..utils.trace import span
 
 log = get_logger("consensus.engine")
 PK = core.StepPlan.Kind
@@ -210,12 +211,14 @@ class Engine:
             self.metrics.inc("kv.cow_copies", len(plan.copy_src))
         t0 = time.perf_counter()
         if plan.kind == PK.Prefill:
-            self._prefill(plan)
+            with span(f"{self.name}.prefill", "engine", tokens=len(plan.token_ids)):
+                self._prefill(plan)
             self.metrics.inc("prefill.steps")
             self.metrics.inc("prefill.tokens", len(plan.token_ids))
             self.metrics.inc("prefill.seconds", time.perf_counter() - t0)
         else:
-            self._decode(plan)
+            with span(f"{self.name}.decode", "engine", seqs=len(plan.seq_ids)):
+                self._decode(plan)
             self.metrics.inc("decode.steps")
             self.metrics.inc("decode.tokens", len(plan.seq_ids))
             self.metrics.inc("decode.seconds", time.perf_counter() - t0)

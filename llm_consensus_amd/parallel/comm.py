@@ -57,6 +57,19 @@ class Comm:
         """Logical AND across ranks: the collective form of 'every member voted Good'."""
         return flag
 
+    def broadcast_object(self, obj, src: int = 0):
+        """Host-side broadcast of a small picklable object (texts, vote records)."""
+        return obj
+
+    def all_gather_object(self, obj) -> list:
+        return [obj]
+
+    def subgroup(self, ranks: Sequence[int]) -> "Comm":
+        """Communicator over ``ranks`` (ranks of THIS communicator, ascending). Collective:
+        every rank of this communicator must call it with the same arguments in the same
+        order; ranks outside ``ranks`` get None."""
+        return self if list(ranks) == [self.rank] or self.world == 1 else None  # type: ignore[return-value]
+
 
 class SingleComm(Comm):
     pass
@@ -85,7 +98,7 @@ class TorchDistComm(Comm):
         return out
 
     def broadcast(self, t: torch.Tensor, src: int = 0) -> torch.Tensor:
-        self.dist.broadcast(t, src=src, group=self.group)
+        self.dist.broadcast(t, src=self._global(src), group=self.group)
         return t
 
     def all_to_all_rows(self, t: torch.Tensor, send_counts: Sequence[int], recv_counts: Sequence[int]) -> torch.Tensor:
@@ -112,6 +125,26 @@ class TorchDistComm(Comm):
         self.dist.all_reduce(t, op=self.dist.ReduceOp.MIN, group=self.group)
         return bool(t.item())
 
+    def _global(self, group_rank: int) -> int:
+        return self.dist.get_global_rank(self.group, group_rank) if self.group is not None else group_rank
+
+    def broadcast_object(self, obj, src: int = 0):
+        box = [obj if self.rank == src else None]
+        self.dist.broadcast_object_list(box, src=self._global(src), group=self.group, device=self.device)
+        return box[0]
+
+    def all_gather_object(self, obj) -> list:
+        out: List[object] = [None] * self.world
+        self.dist.all_gather_object(out, obj, group=self.group)
+        return out
+
+    def subgroup(self, ranks: Sequence[int]) -> Optional["Comm"]:
+        ranks = list(ranks)
+        g = self.dist.new_group([self._global(r) for r in ranks])   # collective over the default group
+        if self.rank not in ranks:
+            return None
+        return SingleComm() if len(ranks) == 1 else TorchDistComm(self.dist, self.device, g)
+
 
 class LoopbackHub:
     """Shared state of a set of LoopbackComm ranks that run as threads of one process
@@ -126,6 +159,8 @@ class LoopbackHub:
         self.barrier = threading.Barrier(world)
         self.slots: List[Optional[torch.Tensor]] = [None] * world
         self.objs: List[object] = [None] * world
+        self.lock = threading.Lock()
+        self.children: dict = {}
 
 
 class LoopbackComm(Comm):
@@ -184,6 +219,34 @@ class LoopbackComm(Comm):
 
     def all_true(self, flag: bool) -> bool:
         return all(bool(p.item()) for p in self._exchange(torch.tensor([1 if flag else 0])))
+
+    def broadcast_object(self, obj, src: int = 0):
+        if self.rank == src:
+            self.hub.objs[src] = obj
+        self.hub.barrier.wait()
+        out = self.hub.objs[src]
+        self.hub.barrier.wait()
+        return out
+
+    def all_gather_object(self, obj) -> list:
+        self.hub.objs[self.rank] = obj
+        self.hub.barrier.wait()
+        out = list(self.hub.objs)
+        self.hub.barrier.wait()
+        return out
+
+    def subgroup(self, ranks: Sequence[int]) -> Optional["Comm"]:
+        ranks = list(ranks)
+        # Every rank counts every call (member of the new group or not), so the counter
+        # names the same group on all ranks, as creation order does for process groups.
+        seq = self._subgroup_calls = getattr(self, "_subgroup_calls", 0) + 1
+        if self.rank not in ranks:
+            return None
+        if len(ranks) == 1:
+            return SingleComm()
+        with self.hub.lock:
+            hub = self.hub.children.setdefault((tuple(ranks), seq), LoopbackHub(len(ranks)))
+        return LoopbackComm(hub, ranks.index(self.rank))
 
 
 def run_loopback(world: int, fn) -> list:

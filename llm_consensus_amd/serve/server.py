@@ -388,9 +388,26 @@ def main(argv: Optional[list] = None) -> int:
     ap.add_argument("--port", type=int, default=8000)
     ap.add_argument("--max-batch", type=int, default=64)
     ap.add_argument("--batch-window-ms", type=float, default=5.0)
+    ap.add_argument("--distributed", action="store_true",
+                    help="one process per GPU under torch.distributed.run; rank 0 serves HTTP")
     args = ap.parse_args(argv)
-    ens = build_ensemble(load_config(args.config))
-    ConsensusServer(ens, args.host, args.port, args.max_batch, args.batch_window_ms).serve_forever()
+    cfg = load_config(args.config)
+    if args.distributed:
+        from ..parallel.ensemble_parallel import DistributedEnsemble, LeaderEnsemble, follow, init_distributed
+
+        comm, device = init_distributed()
+        dist_ens = DistributedEnsemble(cfg, comm, device)
+        if comm.rank != 0:
+            follow(dist_ens)
+            return 0
+        ens = LeaderEnsemble(dist_ens)
+    else:
+        ens = build_ensemble(cfg)
+    try:
+        ConsensusServer(ens, args.host, args.port, args.max_batch, args.batch_window_ms).serve_forever()
+    finally:
+        if args.distributed:
+            ens.close()
     return 0
 
 

@@ -431,3 +431,70 @@ def test_moe_ffn_matches_reference(T):
             want[t] += w[t, k] * (a.to(torch.bfloat16).float() @ Wd[e].float().t())
     assert rel_err(cpu, want) < 1.5e-2
     assert rel_err(gpu, want) < 1.5e-2
+
+
+@pytest.mark.parametrize("T", [5, 130])
+def test_moe_expert_shards_sum_to_full(T):
+    """Expert-parallel building block: each shard's partial output (pairs routed to
+    non-resident experts contribute zero) must add up to the unsharded FFN."""
+    d, dff, E, topk = 256, 384, 8, 2
+    x = bf(rand(T, d, scale=0.7)).to(DEV)
+    Wr = bf(rand(E, d, scale=0.2, seed=1)).to(DEV)
+    Wg, Wu = bf(rand(E, dff, d, scale=0.1, seed=2)), bf(rand(E, dff, d, scale=0.1, seed=3))
+    Wd = bf(rand(E, d, dff, scale=0.1, seed=4))
+    Wgu = torch.stack([ops.interleave_gate_up(Wg[e], Wu[e]) for e in range(E)])
+    full = ops.moe_ffn(x, Wr, ops.ExpertWeights.from_dense(Wgu, DEV, True), ops.ExpertWeights.from_dense(Wd, DEV), topk)
+    acc = torch.zeros(T, d, device=DEV)
+    for lo in range(0, E, 2):
+        part = ops.moe_ffn(x, Wr, ops.ExpertWeights.from_dense(Wgu[lo:lo + 2], DEV, True),
+                           ops.ExpertWeights.from_dense(Wd[lo:lo + 2], DEV), topk, expert_lo=lo)
+        acc += part.float()
+    assert rel_err(acc, full.float()) < 1e-2
+
+
+def test_expert_parallel_model_on_gpu_matches_single():
+    """Two loopback ranks on one GPU, both exchange schemes, against the unsharded model."""
+    from llm_consensus_amd._native import core
+    from llm_consensus_amd.engine.engine import Engine
+    from llm_consensus_amd.models.config import get_preset
+    from llm_consensus_amd.models.transformer import TransformerModel
+    from llm_consensus_amd.parallel.comm import run_loopback
+
+    cfg = get_preset("tiny-mixtral")
+    prompt, targets = list(range(3, 60)), [1, 65, 66, 300]
+
+    def probe(model):
+        eng = Engine(model, num_kv_blocks=32, block_size=64, use_graphs=False)
+        rid = eng.submit(prompt, core.RequestKind.Score, score_ids=targets)
+        eng.run_until_done()
+        return np.array(eng.pop_result(rid).scores)
+
+    want = probe(TransformerModel.random_init(cfg, DEV, seed=5, std=0.08))
+    for mode in ("allreduce", "a2a"):
+        res = run_loopback(2, lambda comm: probe(TransformerModel.random_init(cfg, DEV, seed=5, std=0.08, comm=comm,
+                                                                             ep_size=2, ep_mode=mode)))
+        for got in res:
+            assert np.allclose(got, want, atol=0.06), (mode, got, want)
+
+
+def test_tensor_parallel_model_on_gpu_matches_single():
+    from llm_consensus_amd._native import core
+    from llm_consensus_amd.engine.engine import Engine
+    from llm_consensus_amd.models.config import get_preset
+    from llm_consensus_amd.models.transformer import TransformerModel
+    from llm_consensus_amd.parallel.comm import run_loopback
+
+    cfg = get_preset("small-llama")
+    prompt, targets = list(range(3, 90)), [1, 65, 66, 300]
+
+    def probe(model):
+        eng = Engine(model, num_kv_blocks=32, block_size=64, use_graphs=False)
+        rid = eng.submit(prompt, core.RequestKind.Score, score_ids=targets)
+        eng.run_until_done()
+        return np.array(eng.pop_result(rid).scores)
+
+    want = probe(TransformerModel.random_init(cfg, DEV, seed=6, std=0.05))
+    res = run_loopback(2, lambda comm: probe(TransformerModel.random_init(cfg, DEV, seed=6, std=0.05, tp_rank=comm.rank,
+                                                                         tp_size=2, comm=comm)))
+    for got in res:
+        assert np.allclose(got, want, atol=0.06), (got, want)

@@ -106,3 +106,115 @@ def test_gloo_two_process_collectives_and_replica_bench_path(tmp_path):
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     assert sorted(p.name for p in tmp_path.glob("ok.*")) == ["ok.0", "ok.1"]
+
+
+# ---------------------------------------------------------------- ensemble parallelism
+def _spread_cfg(strategy="majority_vote", judge_tp=0):
+    from llm_consensus_amd.config import config_from_dict
+
+    d = {"strategy": strategy, "decision_mode": "logprob", "placement": "spread",
+         "sampling": {"temperature": 0.0, "max_new_tokens": 6},
+         "models": {"m0": {"preset": "tiny-llama", "seed": 1}, "m1": {"preset": "tiny-qwen", "seed": 2},
+                    "m2": {"preset": "tiny-mistral", "seed": 3}},
+         "members": [{"name": "a", "model": "m0"}, {"name": "b", "model": "m1"}, {"name": "c", "model": "m2"}]}
+    if judge_tp:
+        d["models"]["judge"] = {"preset": "tiny-llama", "seed": 9, "tp": judge_tp}
+        d["members"].append({"name": "judge", "model": "judge", "role": "judge"})
+    return config_from_dict(d)
+
+
+QUESTIONS = [f"Question {i}: pick. A) a B) b C) c D) d" for i in range(5)]
+
+
+def test_members_on_different_ranks_match_single_process():
+    from llm_consensus_amd.app import build_ensemble
+    from llm_consensus_amd.parallel.ensemble_parallel import DistributedEnsemble
+
+    cfg = _spread_cfg()
+    want = build_ensemble(cfg, torch.device("cpu")).ask_many(QUESTIONS)
+
+    def rank(comm):
+        ens = DistributedEnsemble(cfg, comm, torch.device("cpu"))
+        assert ens.layout.num_replicas == 1 and len(ens.layout.hosted) == 1      # one model per rank
+        return [(r.answer, [v["class"] for v in r.votes]) for r in ens.ask_many(QUESTIONS)]
+
+    res = run_loopback(3, rank)
+    assert res[0] == res[1] == res[2]
+    assert res[0] == [(r.answer, [v["class"] for v in r.votes]) for r in want]
+
+
+def test_two_replicas_shard_questions():
+    from llm_consensus_amd.app import build_ensemble
+    from llm_consensus_amd.parallel.ensemble_parallel import DistributedEnsemble
+
+    cfg = _spread_cfg()
+    want = [r.answer for r in build_ensemble(cfg, torch.device("cpu")).ask_many(QUESTIONS)]
+
+    def rank(comm):
+        ens = DistributedEnsemble(cfg, comm, torch.device("cpu"))
+        assert ens.layout.num_replicas == 2 and ens.layout.replica == comm.rank // 3
+        return [r.answer for r in ens.ask_many(QUESTIONS)]
+
+    for got in run_loopback(6, rank):
+        assert got == want
+
+
+def test_tensor_parallel_judge_next_to_single_gpu_proposers():
+    from llm_consensus_amd.parallel.ensemble_parallel import DistributedEnsemble
+
+    cfg = _spread_cfg("judge_logprob", judge_tp=2)
+
+    def rank(comm):
+        ens = DistributedEnsemble(cfg, comm, torch.device("cpu"))
+        lay = ens.layout
+        if "judge" in lay.hosted:
+            assert lay.hosted["judge"].world == 2
+            assert ens.backends["judge"].local.engine.model.tp_size == 2
+        res = ens.ask_many(QUESTIONS[:3])
+        return sorted(lay.hosted), [(r.answer, r.strategy) for r in res]
+
+    res = run_loopback(5, rank)
+    hosted = [h for h, _ in res]
+    assert sum("judge" in h for h in hosted) == 2 and all(len(h) == 1 for h in hosted)
+    answers = [a for _, a in res]
+    assert all(a == answers[0] for a in answers) and all(s == "judge_logprob" for _, s in answers[0])
+
+
+def test_reference_protocol_runs_in_lock_step_across_ranks():
+    """The unanimity loop with random proposer / refiner picks must take identical decisions on
+    every rank of a replica (seeded sessions), with members served by a sharded backend."""
+    from llm_consensus_amd.config import ConsensusConfig
+    from llm_consensus_amd.consensus.backend import ScriptedBackend
+    from llm_consensus_amd.parallel.ensemble_parallel import DistributedEnsemble, ShardedBackend
+
+    cfg = ConsensusConfig(seed=5)
+
+    def rank(comm):
+        script = {"propose": ["draft"], "evaluate": ["NeedsRefinement\nno"] * 2 + ["Good\nyes"] * 30, "refine": ["better"]}
+        ens = DistributedEnsemble(cfg, comm, torch.device("cpu"), backend_factory=lambda spec, gc: ScriptedBackend(script))
+        assert isinstance(ens.backends["default"], ShardedBackend)
+        r = ens.ask("why?")
+        return r.answer, r.rounds, r.proposer
+
+    res = run_loopback(2, rank)          # one model, two GPUs -> two replicas; one question -> replica 0 answers
+    assert res[0] == res[1] and res[0][0] in ("draft", "better")
+
+
+def test_leader_follower_serving_loop():
+    from llm_consensus_amd.parallel.ensemble_parallel import DistributedEnsemble, LeaderEnsemble, follow
+
+    cfg = _spread_cfg()
+
+    def rank(comm):
+        ens = DistributedEnsemble(cfg, comm, torch.device("cpu"))
+        if comm.rank != 0:
+            return follow(ens)
+        lead = LeaderEnsemble(ens)
+        a = [r.answer for r in lead.ask_many(QUESTIONS[:2])]
+        b = lead.ask(QUESTIONS[0]).answer
+        lead.close()
+        return a, b
+
+    res = run_loopback(3, rank)
+    assert res[1] == res[2] == 2                      # followers took part in both batches
+    assert res[0][0][0] == res[0][1]
