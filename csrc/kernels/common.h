@@ -50,6 +50,12 @@ LC_DEVICE float wave_max(float v) {
   return v;
 }
 
+LC_DEVICE int wave_max_int(int v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v = max(v, __shfl_xor(v, off, 64));
+  return v;
+}
+
 // Block-wide reductions for blocks of up to 16 waves; `scratch` needs 16 floats.
 LC_DEVICE float block_sum(float v, float* scratch) {
   v = wave_sum(v);

@@ -178,7 +178,63 @@ __global__ void judge_reduce_kernel(const float* __restrict__ scores, int R, int
   }
 }
 
+// Answer extraction on token ids: for each generated sequence find the LAST occurrence of
+// the marker token string (e.g. the tokens of "Answer:") and classify the first token among
+// the next `window` tokens that is one of the C choice tokens; -1 if there is no marker or no
+// choice token follows it. With an empty marker the whole sequence is the window and the
+// LAST choice token wins. One wave per row; lanes test positions in parallel and the wave
+// keeps the largest matching position.
+__global__ void answer_extract_kernel(const int32_t* __restrict__ ids, const int32_t* __restrict__ lens,
+                                      int R, int ld, const int32_t* __restrict__ marker, int P,
+                                      const int32_t* __restrict__ choice_ids, int C, int window,
+                                      int32_t* __restrict__ cls) {
+  const int r = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (r >= R) return;
+  const int32_t* row = ids + static_cast<size_t>(r) * ld;
+  const int n = min(lens[r], ld);
+  auto class_of = [&](int tok) {
+    for (int c = 0; c < C; ++c)
+      if (choice_ids[c] == tok) return c;
+    return -1;
+  };
+  if (P == 0) {
+    int best = -1;  // position of the last choice token
+    for (int p = lane; p < n; p += 64)
+      if (class_of(row[p]) >= 0) best = p;
+    best = wave_max_int(best);
+    if (lane == 0) cls[r] = best >= 0 ? class_of(row[best]) : -1;
+    return;
+  }
+  int last = -1;
+  for (int p = lane; p + P <= n; p += 64) {
+    bool ok = true;
+    for (int j = 0; j < P && ok; ++j) ok = row[p + j] == marker[j];
+    if (ok) last = p;
+  }
+  last = wave_max_int(last);
+  if (lane == 0) {
+    int out = -1;
+    if (last >= 0) {
+      const int lo = last + P, hi = min(n, lo + window);
+      for (int p = lo; p < hi && out < 0; ++p) out = class_of(row[p]);
+    }
+    cls[r] = out;
+  }
+}
+
 }  // namespace
+
+LC_EXPORT int lc_answer_extract(const void* ids, const void* lens, int R, int ld, const void* marker, int P,
+                                const void* choice_ids, int C, int window, void* cls, hipStream_t stream) {
+  if (R <= 0) return 0;
+  if (C < 1 || P < 0 || ld < 1) return -1;
+  answer_extract_kernel<<<dim3((R + 3) / 4), dim3(256), 0, stream>>>(
+      static_cast<const int32_t*>(ids), static_cast<const int32_t*>(lens), R, ld,
+      static_cast<const int32_t*>(marker), P, static_cast<const int32_t*>(choice_ids), C, window,
+      static_cast<int32_t*>(cls));
+  LC_RETURN_LAST_ERROR();
+}
 
 LC_EXPORT int lc_majority_vote(const void* votes, int R, int N, int num_classes, int tie, void* winner,
                                void* count, void* valid, void* agreement, void* unanimous,

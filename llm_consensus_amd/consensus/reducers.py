@@ -84,3 +84,33 @@ def judge_reduce_batch(scores: np.ndarray, device=None) -> JudgeBatch:
 def unanimity(verdict_logprobs: np.ndarray) -> "core.UnanimityResult":
     """[N, 2] (log P Good, log P NeedsRefinement) -> all_good flag + dissenters."""
     return core.unanimity_from_logprobs(np.ascontiguousarray(verdict_logprobs, dtype=np.float32))
+
+
+def answer_extract(ids: np.ndarray, lens: np.ndarray, marker, choice_ids, window: int = 4, device=None) -> np.ndarray:
+    """Token-level answer extraction: class of the first choice token within ``window``
+    tokens after the last occurrence of ``marker`` (a token-id sequence), -1 if none. An
+    empty marker means "the last choice token anywhere". The text-level parser
+    (``core.extract_choice``) stays authoritative; this one spares the detokenise + regex
+    round trip when answers follow a fixed cue such as ``Answer:``."""
+    ids = np.ascontiguousarray(ids, dtype=np.int32)
+    lens = np.ascontiguousarray(lens, dtype=np.int32)
+    if _is_gpu(device):
+        import torch
+
+        from ..ops.consensus_ops import answer_extract_device
+
+        return answer_extract_device(torch.from_numpy(ids).to(device), torch.from_numpy(lens).to(device), marker,
+                                     choice_ids, window).cpu().numpy()
+    marker, choice = list(marker), {int(t): c for c, t in reversed(list(enumerate(choice_ids)))}
+    out = np.full(ids.shape[0], -1, dtype=np.int32)
+    P = len(marker)
+    for r in range(ids.shape[0]):
+        row = ids[r, : min(int(lens[r]), ids.shape[1])].tolist()
+        if P == 0:
+            hits = [t for t in row if t in choice]
+            out[r] = choice[hits[-1]] if hits else -1
+            continue
+        last = max((p for p in range(len(row) - P + 1) if row[p:p + P] == marker), default=-1)
+        if last >= 0:
+            out[r] = next((choice[t] for t in row[last + P: last + P + window] if t in choice), -1)
+    return out

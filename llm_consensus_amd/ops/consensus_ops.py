@@ -70,3 +70,16 @@ def judge_reduce_device(scores: np.ndarray, device):
     unan = torch.empty(R, dtype=torch.int32, device=device)
     h.call("lc_judge_reduce", s.data_ptr(), R, C, J, winner.data_ptr(), score.data_ptr(), unan.data_ptr())
     return JudgeBatch(winner.cpu().numpy(), score.cpu().numpy(), unan.cpu().numpy().astype(bool))
+
+
+def answer_extract_device(ids: torch.Tensor, lens: torch.Tensor, marker, choice_ids, window: int = 4) -> torch.Tensor:
+    """Class id per generated sequence from token ids already on the GPU (int32 [R, Tmax],
+    lens int32 [R]); see answer_extract_kernel. Returns int32 [R] on the device."""
+    R, ld = ids.shape
+    dev = ids.device
+    mk = torch.tensor(list(marker) or [0], dtype=torch.int32, device=dev)
+    ch = torch.tensor(list(choice_ids), dtype=torch.int32, device=dev)
+    out = torch.empty(R, dtype=torch.int32, device=dev)
+    h.call("lc_answer_extract", ids.data_ptr(), lens.data_ptr(), R, ld, mk.data_ptr(), len(marker), ch.data_ptr(),
+           len(choice_ids), window, out.data_ptr())
+    return out

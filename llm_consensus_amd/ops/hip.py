@@ -40,6 +40,7 @@ _SIGNATURES = {
     "lc_majority_vote": [_P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P],
     "lc_cosine_medoid": [_P, _I, _I, _I, _L, _P, _P, _P, _P],
     "lc_judge_reduce": [_P, _I, _I, _I, _P, _P, _P, _P],
+    "lc_answer_extract": [_P, _P, _I, _I, _P, _I, _P, _I, _I, _P, _P],
     "lc_moe_router": [_P, _P, _I, _I, _I, _I, _P, _P, _P, _P],
     "lc_moe_permute": [_P, _I, _I, _I, _P, _P, _P, _P],
     "lc_moe_combine": [_P, _P, _P, _P, _I, _I, _I, _P],

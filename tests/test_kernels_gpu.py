@@ -498,3 +498,22 @@ def test_tensor_parallel_model_on_gpu_matches_single():
                                                                          tp_size=2, comm=comm)))
     for got in res:
         assert np.allclose(got, want, atol=0.06), (got, want)
+
+
+def test_answer_extract_matches_host():
+    from llm_consensus_amd.consensus import reducers
+
+    rng = np.random.default_rng(3)
+    R, T = 300, 90
+    ids = rng.integers(0, 40, size=(R, T)).astype(np.int32)
+    lens = rng.integers(0, T + 1, size=R).astype(np.int32)
+    marker, choices = [7, 8], [30, 31, 32, 33]
+    for r in range(0, R, 3):                       # plant cues
+        p = int(rng.integers(0, T - 4))
+        ids[r, p:p + 2] = marker
+        ids[r, p + 2 + int(rng.integers(0, 3))] = choices[int(rng.integers(0, 4))]
+    for mk, win in ((marker, 3), (marker, 1), ([], 4), ([7], 5)):
+        host = reducers.answer_extract(ids, lens, mk, choices, win)
+        dev = reducers.answer_extract(ids, lens, mk, choices, win, device=DEV)
+        assert np.array_equal(host, dev), (mk, win)
+    assert (host >= 0).any() and (host < 0).any()

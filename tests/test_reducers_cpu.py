@@ -50,3 +50,18 @@ def test_judge_reduce_and_unanimity():
     assert out.winner[0] == 1 and not out.unanimous[0]
     u = reducers.unanimity(np.array([[0, -1], [-2, -1], [0, -3]], dtype=np.float32))
     assert not u.all_good and u.dissenters == [1]
+
+
+def test_answer_extract_host():
+    from llm_consensus_amd.consensus import reducers
+
+    marker, choices = [10, 11], [65, 66, 67, 68]
+    ids = np.array([[1, 10, 11, 66, 0, 0, 0, 0],        # B after the cue
+                    [10, 11, 65, 5, 10, 11, 9, 68],     # last cue wins; D is 2 tokens after it
+                    [65, 66, 67, 68, 1, 2, 3, 4],       # no cue
+                    [10, 11, 1, 2, 3, 4, 5, 66],        # choice outside the window
+                    [1, 2, 10, 11, 67, 9, 9, 9]], dtype=np.int32)
+    lens = np.array([4, 8, 8, 8, 4], dtype=np.int32)       # row 4: the cue is cut off by its length
+    got = reducers.answer_extract(ids, lens, marker, choices, window=3)
+    assert got.tolist() == [1, 3, -1, -1, -1]
+    assert reducers.answer_extract(ids, lens, [], choices).tolist() == [1, 3, 3, 1, -1]
