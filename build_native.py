@@ -7,7 +7,7 @@
   (hipcc --offload-arch=gfx950); cross-compiles on hosts without a GPU.
 
 Objects are cached under ``build/`` and rebuilt only when a source or header is newer.
-Usage: ``python build_native.py [core] [kernels] [--force] [-j N]``.
+Usage: ``python build_native.py [core] [kernels] [selftest --sanitize=thread] [--force] [-j N]``.
 """
 from __future__ import annotations
 
@@ -53,7 +53,7 @@ def build_core(force: bool = False, jobs: int = 8) -> Path:
     import pybind11
 
     src_dir = ROOT / "csrc" / "core"
-    srcs = sorted(src_dir.glob("*.cpp"))
+    srcs = [s for s in sorted(src_dir.glob("*.cpp")) if s.name != "selftest.cpp"]
     hdrs = sorted(src_dir.glob("*.hpp"))
     obj_dir = BUILD_DIR / "core"
     obj_dir.mkdir(parents=True, exist_ok=True)
@@ -71,6 +71,20 @@ def build_core(force: bool = False, jobs: int = 8) -> Path:
     out = core_path()
     if force or todo or _newer_than(out, objs):
         _run(["g++", "-shared", "-o", str(out), *map(str, objs)])
+    return out
+
+
+def build_selftest(sanitize: str = "address,undefined") -> Path:
+    """Stand-alone stress driver of the host core (csrc/core/selftest.cpp) under a host
+    sanitizer: ``address,undefined`` or ``thread``. Host code only; GPU code is never
+    built with sanitizers."""
+    src_dir = ROOT / "csrc" / "core"
+    srcs = [s for s in sorted(src_dir.glob("*.cpp")) if s.name != "bindings.cpp"]
+    out = BUILD_DIR / ("selftest_" + sanitize.replace(",", "_"))
+    BUILD_DIR.mkdir(parents=True, exist_ok=True)
+    static = "-static-libtsan" if sanitize == "thread" else "-static-libasan"
+    _run(["g++", "-std=c++17", "-O1", "-g", "-fno-omit-frame-pointer", f"-fsanitize={sanitize}", static,
+          "-fno-sanitize-recover=all", f"-I{src_dir}", *map(str, srcs), "-o", str(out), "-lpthread"])
     return out
 
 
@@ -103,7 +117,10 @@ def main() -> None:
     ap.add_argument("targets", nargs="*", default=["core", "kernels"])
     ap.add_argument("--force", action="store_true")
     ap.add_argument("-j", "--jobs", type=int, default=min(8, os.cpu_count() or 1))
+    ap.add_argument("--sanitize", default="address,undefined", help="sanitizer set of the 'selftest' target")
     a = ap.parse_args()
+    if "selftest" in a.targets:
+        print("built", build_selftest(a.sanitize))
     if "core" in a.targets:
         print("built", build_core(a.force, a.jobs))
     if "kernels" in a.targets:
