@@ -107,14 +107,28 @@ class Backend:
         """Exchange phase of run(): publish results to ranks that do not host this backend
         (a no-op for backends that live entirely in this process)."""
 
+    def engines(self) -> list:
+        """In-process engines this backend would drive in run_local() (empty for remote or
+        scripted backends); lets a driver overlap the steps of several engines."""
+        return []
+
     def stats(self) -> Dict[str, float]:
         return {}
 
 
 def run_backends(backends: Sequence["Backend"]) -> None:
-    """Completes the submitted requests of several backends. All compute phases are started
-    before any exchange phase, so backends hosted on different GPUs work concurrently and a
-    rank that hosts none of them waits only once."""
+    """Completes the submitted requests of several backends. Engines that live in this
+    process are stepped together with their GPU work overlapped on separate streams; all
+    compute phases are started before any exchange phase, so backends hosted on different
+    GPUs work concurrently and a rank that hosts none of them waits only once."""
+    engines = [e for b in backends for e in b.engines()]
+    if len(engines) > 1:
+        from ..engine.engine import run_engines
+
+        try:
+            run_engines(engines)
+        except Exception:   # the per-backend pass below reports the failure on the right handles
+            pass
     for b in backends:
         b.run_local()
     for b in backends:

@@ -30,7 +30,7 @@ from .._native import core
 from ..utils.log import get_logger
 from ..utils.trace import span
 from . import reducers
-from .backend import BackendError, GenParams
+from .backend import BackendError, GenParams, run_backends
 from .members import Member, distinct_backends
 from .protocol import ConsensusResult
 
@@ -39,11 +39,8 @@ log = get_logger("consensus.strategy")
 
 def _run_all(members: Sequence[Member], phase: str = "generate") -> None:
     backends = distinct_backends(list(members))
-    for b in backends:
-        with span(f"{phase}:{b.name}", "strategy"):
-            b.run_local()
-    for b in backends:
-        b.sync()
+    with span(f"{phase}:" + "+".join(b.name for b in backends), "strategy"):
+        run_backends(backends)
 
 
 def _classify(text: str, decision_lp: Optional[List[float]], choices: str) -> int:

@@ -95,5 +95,8 @@ class EngineBackend(Backend):
                 h.set_result(out.embedding)
         self._pending.clear()
 
+    def engines(self) -> list:
+        return [self.engine] if self._pending else []
+
     def stats(self) -> Dict[str, float]:
         return self.engine.stats()

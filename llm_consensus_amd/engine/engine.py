@@ -9,6 +9,7 @@ moves small int32 arrays per step; tokens are sampled on device.
 """
 from __future__ import annotations
 
+import contextlib
 import time
 from dataclasses import dataclass, field
 from typing import Dict, List, Optional, Sequence
@@ -162,6 +163,11 @@ class Engine:
         self.use_graphs = (self.device.type == "cuda") if use_graphs is None else (use_graphs and self.device.type == "cuda")
         self.graph_buckets = sorted(b for b in graph_buckets if b <= max_batch_seqs) or [max_batch_seqs]
         self.graph_pool = None
+        # Every engine issues its GPU work on a stream of its own, so the engines of one
+        # ensemble can have steps in flight at the same time (see run_engines).
+        self.stream = torch.cuda.Stream(device=self.device) if self.device.type == "cuda" else None
+        if self.stream is not None:
+            self.stream.wait_stream(torch.cuda.current_stream(self.device))   # weights were written there
         self._graphs: Dict[tuple, _DecodeGraph] = {}
         self._reqs: Dict[int, _ReqState] = {}
         self._done: Dict[int, RequestOutput] = {}
@@ -202,30 +208,52 @@ class Engine:
         # Blocking copy: the source is a temporary pageable buffer that dies with this call.
         return torch.from_numpy(np.ascontiguousarray(a)).to(device=self.device, dtype=dtype)
 
-    def step(self) -> bool:
+    def _on_stream(self):
+        return torch.cuda.stream(self.stream) if self.stream is not None else contextlib.nullcontext()
+
+    def begin_step(self):
+        """Schedules one step and enqueues its GPU work on the engine's stream without waiting
+        for it. Returns an opaque token for ``end_step`` (None when idle)."""
         plan = self.sched.schedule()
         if plan.kind == PK.Idle:
-            return False
-        if len(plan.copy_src):
-            self.kv.copy_blocks(self._dev(plan.copy_src), self._dev(plan.copy_dst))
-            self.metrics.inc("kv.cow_copies", len(plan.copy_src))
+            return None
         t0 = time.perf_counter()
-        if plan.kind == PK.Prefill:
-            with span(f"{self.name}.prefill", "engine", tokens=len(plan.token_ids)):
-                self._prefill(plan)
-            self.metrics.inc("prefill.steps")
-            self.metrics.inc("prefill.tokens", len(plan.token_ids))
-            self.metrics.inc("prefill.seconds", time.perf_counter() - t0)
-        else:
-            with span(f"{self.name}.decode", "engine", seqs=len(plan.seq_ids)):
-                self._decode(plan)
-            self.metrics.inc("decode.steps")
-            self.metrics.inc("decode.tokens", len(plan.seq_ids))
-            self.metrics.inc("decode.seconds", time.perf_counter() - t0)
+        with self._on_stream():
+            if len(plan.copy_src):
+                self.kv.copy_blocks(self._dev(plan.copy_src), self._dev(plan.copy_dst))
+                self.metrics.inc("kv.cow_copies", len(plan.copy_src))
+            if plan.kind == PK.Prefill:
+                with span(f"{self.name}.prefill", "engine", tokens=len(plan.token_ids)):
+                    state = self._prefill_launch(plan)
+            else:
+                with span(f"{self.name}.decode", "engine", seqs=len(plan.seq_ids)):
+                    state = self._decode_launch(plan)
+        return plan, state, t0
+
+    def end_step(self, token) -> None:
+        """Waits for the step started by ``begin_step`` and does its bookkeeping."""
+        plan, state, t0 = token
+        with self._on_stream():
+            if plan.kind == PK.Prefill:
+                self._prefill_finish(plan, state)
+                self.metrics.inc("prefill.steps")
+                self.metrics.inc("prefill.tokens", len(plan.token_ids))
+                self.metrics.inc("prefill.seconds", time.perf_counter() - t0)
+            else:
+                self._decode_finish(plan, state)
+                self.metrics.inc("decode.steps")
+                self.metrics.inc("decode.tokens", len(plan.seq_ids))
+                self.metrics.inc("decode.seconds", time.perf_counter() - t0)
         self._collect()
+
+    def step(self) -> bool:
+        token = self.begin_step()
+        if token is None:
+            return False
+        self.end_step(token)
         return True
 
-    def _prefill(self, plan) -> None:
+    def _prefill_launch(self, plan):
         m = self.model
         tok = self._dev(plan.token_ids)
         meta = AttnMeta(is_prefill=True, block_tables=self._dev(plan.block_tables), ctx_lens=self._dev(plan.context_lens),
@@ -241,8 +269,7 @@ class Engine:
                 s = rows.sum(0)
                 st.embed_sum = s if st.embed_sum is None else st.embed_sum + s
                 st.embed_count += rows.shape[0]
-        first_tokens = np.zeros(0, dtype=np.int32)
-        first_lps = np.zeros(0, dtype=np.float32)
+        toks = lps = logits = None
         if len(plan.last_rows):
             rows = hidden[self._dev(plan.last_rows, torch.int64)]
             logits = m.logits(rows)
@@ -256,7 +283,16 @@ class Engine:
                     self._dev(np.array([s.top_k for s in slots], dtype=np.int32)),
                     self._dev(np.array([s.seed for s in slots], dtype=np.int64), torch.int64),
                     self._dev(np.zeros(len(slots), dtype=np.int32)), ri)
-                first_tokens, first_lps = toks.cpu().numpy(), lps.cpu().numpy()
+        return toks, lps, logits
+
+    def _prefill_finish(self, plan, state) -> None:
+        toks, lps, logits = state
+        req_ids = plan.request_ids
+        first_tokens = np.zeros(0, dtype=np.int32)
+        first_lps = np.zeros(0, dtype=np.float32)
+        if toks is not None:
+            first_tokens, first_lps = toks.cpu().numpy(), lps.cpu().numpy()
+        if logits is not None:
             # decisions / scores at the prompt's last position
             for j, seq_i in enumerate(plan.last_row_seq):
                 rid = int(req_ids[int(seq_i)])
@@ -278,7 +314,7 @@ class Engine:
                 return b
         return B
 
-    def _decode(self, plan) -> None:
+    def _decode_launch(self, plan):
         B = len(plan.seq_ids)
         gshared = plan.group_shared_blocks
         gcount = plan.group_count
@@ -351,6 +387,12 @@ class Engine:
             tok, lp, dl = g.out_tokens, g.out_lps, g.out_dec
         else:
             tok, lp, dl = g.run_body(self)
+        return tok, lp, dl, any_decision
+
+    def _decode_finish(self, plan, state) -> None:
+        tok, lp, dl, any_decision = state
+        B = len(plan.seq_ids)
+        req_ids = plan.request_ids
         tok_h = tok[:B].cpu().numpy()
         lp_h = lp[:B].cpu().numpy()
         if any_decision:
@@ -394,3 +436,27 @@ class Engine:
             "kv.cow_copies_total": k.cow_copies, "kv.evictions": k.evictions,
         })
         return s
+
+
+def run_engines(engines: Sequence["Engine"]) -> None:
+    """Drives several engines to completion with their steps overlapped: each engine's next
+    step is enqueued on its own stream as soon as its previous one has been collected, so up
+    to len(engines) steps are in flight. Decode steps of 7-8B models at small batch are
+    dominated by short kernels whose launch ramps and end-of-kernel cache write-backs leave
+    CUs idle; kernels of the other members fill those gaps."""
+    live = [e for e in engines if e.has_work()]
+    if len(live) <= 1:
+        for e in live:
+            e.run_until_done()
+        return
+    pending = {}
+    while live:
+        for e in list(live):
+            tok = pending.pop(e, None)
+            if tok is not None:
+                e.end_step(tok)
+            tok = e.begin_step()
+            if tok is None:
+                live.remove(e)
+            else:
+                pending[e] = tok

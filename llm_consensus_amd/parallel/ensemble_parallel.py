@@ -90,6 +90,9 @@ class ShardedBackend(Backend):
         self.run_local()
         self.sync()
 
+    def engines(self) -> list:
+        return self.local.engines() if self.local is not None else []
+
     def stats(self) -> Dict[str, float]:
         return self.local.stats() if self.local is not None else {}
 

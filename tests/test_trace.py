@@ -45,7 +45,7 @@ def test_engine_strategy_and_protocol_emit_spans():
         ens = build_ensemble(load_config(str(CONFIGS / "plumbing_tiny.toml")), torch.device("cpu"))
         ens.ask("Q? A) a B) b C) c D) d")
         names = set(trace.TRACER.summary())
-        assert {"m0.prefill", "m0.decode", "generate:m0", "reduce"} <= names, names
+        assert {"m0.prefill", "m0.decode", "generate:m0+m1+m2", "reduce"} <= names, names
         trace.TRACER.clear()
         be = ScriptedBackend({"propose": ["a"], "evaluate": ["Good\nok"] * 8})
         build_ensemble(ConsensusConfig(), torch.device("cpu"), backends={"default": be}).ask("why?")
