@@ -248,6 +248,80 @@ __global__ __launch_bounds__(64) void attn_decode_kernel(const bf16_t* __restric
   }
 }
 
+// Multi-wave variant: the block's key range is cut into NW sub-ranges, one per wave, and the
+// NW partial results are merged through LDS by log-sum-exp before anything is written. With
+// nsplit == 1 this produces the final bf16 rows directly: no partial slots in HBM and no
+// separate merge kernel in the decode step. Requires G = Hq/Hkv <= 8.
+template <int DH, int NW>
+__global__ __launch_bounds__(64 * NW) void attn_decode_mw_kernel(
+    const bf16_t* __restrict__ Q, int q_stride, const bf16_t* __restrict__ Kc, const bf16_t* __restrict__ Vt,
+    const int32_t* __restrict__ block_tables, int max_blocks, const int32_t* __restrict__ ctx_lens,
+    const int32_t* __restrict__ kv_begin, bf16_t* __restrict__ out, float* __restrict__ part_o,
+    float* __restrict__ part_lse, int np_total, int Hq, int Hkv, int lbs, float scale2, int window) {
+  __shared__ float sm_o[NW][8][DH];
+  __shared__ float sm_m[NW][8], sm_l[NW][8];
+  const int kvh = blockIdx.x, b = blockIdx.y, split = blockIdx.z, nsplit = gridDim.z;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int G = Hq / Hkv;
+  const int q = lane & 31, hh = lane >> 5;
+  const bool valid = q < G;
+  const int head = kvh * G + q;
+  const int ctx = ctx_lens[b];
+  int begin = kv_begin ? kv_begin[b] : 0;
+  if (window > 0 && ctx > window) begin = max(begin, ctx - window);
+  const int base = begin & ~31;
+  const int ntile = (ctx - base + 31) / 32;
+  const int per_w = (ntile + nsplit * NW - 1) / (nsplit * NW);   // 32-key tiles per wave
+  const int part = split * NW + wave;
+  const int lo = max(begin, base + part * per_w * 32);
+  const int hi = min(ctx, base + (part + 1) * per_w * 32);
+
+  bf16x8 qf[DH / 16];
+  load_q<DH>(qf, valid ? Q + static_cast<size_t>(b) * q_stride + head * DH : nullptr, lane);
+  TileCtx c{Kc, Vt, block_tables + static_cast<size_t>(b) * max_blocks, Hkv, kvh, lbs, 1 << lbs, scale2};
+  AttnState<DH> st;
+  init_state<DH>(st);
+  if (lo < hi) attend_range<DH>(st, qf, c, lo, hi, valid ? lo : 0, valid ? hi : 0, lane);
+
+  const float l_all = st.l + __shfl_xor(st.l, 32, 64);
+  if (valid) {
+    if (hh == 0) {
+      sm_m[wave][q] = st.m;
+      sm_l[wave][q] = l_all;
+    }
+#pragma unroll
+    for (int blk = 0; blk < DH / 32; ++blk)
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4)
+        *reinterpret_cast<f32x4*>(&sm_o[wave][q][blk * 32 + 8 * g4 + 4 * hh]) =
+            f32x4{st.o[blk][4 * g4 + 0], st.o[blk][4 * g4 + 1], st.o[blk][4 * g4 + 2], st.o[blk][4 * g4 + 3]};
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < G * DH; e += 64 * NW) {
+    const int qq = e / DH, d = e % DH;
+    float mx = kNegBig;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) mx = fmaxf(mx, sm_m[w][qq]);
+    float num = 0.f, den = 0.f;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+      const float sc = exp2f(sm_m[w][qq] - mx);
+      num += sc * sm_o[w][qq][d];
+      den += sc * sm_l[w][qq];
+    }
+    const float val = den > 0.f ? num / den : 0.f;
+    const int hd = kvh * G + qq;
+    if (part_o) {
+      const size_t slot = (static_cast<size_t>(b) * Hq + hd) * np_total + split;
+      part_o[slot * DH + d] = val;
+      if (d == 0) part_lse[slot] = den > 0.f ? mx + log2f(den) : kNegBig;
+    } else {
+      out[static_cast<size_t>(b) * (Hq * DH) + hd * DH + d] = f32_to_bf16(val);
+    }
+  }
+}
+
 // ------------------------------------------------------------------ shared-prefix decode
 // Group g = `count` consecutive batch rows starting at `first` whose first
 // `shared_blocks` KV blocks are identical. Rows of the MFMA tile = (chain, q-head in the
@@ -362,11 +436,12 @@ LC_EXPORT int lc_attn_decode(const void* Q, int q_stride, const void* Kc, const 
                              const void* block_tables, int max_blocks, const void* ctx_lens,
                              const void* kv_begin, void* out, void* part_o, void* part_lse, int np_total,
                              int nsplit, int n_seqs, int Hq, int Hkv, int Dh, int block_size, float scale,
-                             int window, hipStream_t stream) {
+                             int window, int waves, hipStream_t stream) {
   if (n_seqs <= 0) return 0;
   if (Hq % Hkv || Hq / Hkv > 32 || (Dh != 64 && Dh != 128) || block_size % 8 ||
       (block_size & (block_size - 1)) || nsplit < 1 || (!part_o && nsplit != 1) || nsplit > np_total)
     return -1;
+  if (waves != 1 && ((waves != 2 && waves != 4) || Hq / Hkv > 8)) return -1;
   const dim3 grid(Hkv, n_seqs, nsplit), block(64);
   const float scale2 = scale * 1.4426950408889634f;
   const int lbs = ilog2(block_size);
@@ -375,8 +450,17 @@ LC_EXPORT int lc_attn_decode(const void* Q, int q_stride, const void* Kc, const 
       static_cast<const int32_t*>(block_tables), max_blocks, static_cast<const int32_t*>(ctx_lens),      \
       static_cast<const int32_t*>(kv_begin), static_cast<bf16_t*>(out), static_cast<float*>(part_o),     \
       static_cast<float*>(part_lse), np_total, Hq, Hkv, lbs, scale2, window
-  if (Dh == 128) attn_decode_kernel<128><<<grid, block, 0, stream>>>(LC_ARGS);
-  else attn_decode_kernel<64><<<grid, block, 0, stream>>>(LC_ARGS);
+  if (waves == 4) {
+    if (Dh == 128) attn_decode_mw_kernel<128, 4><<<grid, dim3(256), 0, stream>>>(LC_ARGS);
+    else attn_decode_mw_kernel<64, 4><<<grid, dim3(256), 0, stream>>>(LC_ARGS);
+  } else if (waves == 2) {
+    if (Dh == 128) attn_decode_mw_kernel<128, 2><<<grid, dim3(128), 0, stream>>>(LC_ARGS);
+    else attn_decode_mw_kernel<64, 2><<<grid, dim3(128), 0, stream>>>(LC_ARGS);
+  } else if (Dh == 128) {
+    attn_decode_kernel<128><<<grid, block, 0, stream>>>(LC_ARGS);
+  } else {
+    attn_decode_kernel<64><<<grid, block, 0, stream>>>(LC_ARGS);
+  }
 #undef LC_ARGS
   LC_RETURN_LAST_ERROR();
 }

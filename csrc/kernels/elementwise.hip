@@ -21,27 +21,52 @@ __global__ void embed_gather_kernel(const int32_t* __restrict__ ids, const bf16_
   for (int c = lane; c < d / 8; c += 64) dst[c] = src[c];
 }
 
-// If `delta` != nullptr: h += delta (h is the bf16 residual stream, updated in place),
-// then y = h * rsqrt(mean(h^2) + eps) * w. With delta == nullptr it is a plain RMSNorm of h.
-// One wave per row; the row stays in registers as packed bf16 (CH chunks of 8 per lane).
-template <int CH>
-__global__ void rmsnorm_kernel(bf16_t* __restrict__ h, const bf16_t* __restrict__ delta,
-                               const bf16_t* __restrict__ w, bf16_t* __restrict__ y, int T, int d,
-                               float eps) {
-  const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-  const int lane = threadIdx.x & 63;
+// Residual add + RMSNorm. The addend is either `delta` (bf16 [T, d]) or, when `part` is
+// given, the sum of S fp32 slabs [S][T][d] left un-reduced by a split-K GEMM (the slab sum
+// happens here instead of in a kernel of its own). With an addend, h += addend (h is the
+// bf16 residual stream, updated in place); then y = h * rsqrt(mean(h^2) + eps) * w.
+// WAVES_PER_ROW = 1: one wave per row, CH chunks of 8 per lane (large T, bandwidth-bound).
+// WAVES_PER_ROW = 4: one 256-thread block per row (decode: few rows, latency-bound, so the
+// row is spread over 4x the lanes and the gain vector is fetched before the reduction).
+template <int CH, int WAVES_PER_ROW>
+__global__ __launch_bounds__(256) void rmsnorm_kernel(bf16_t* __restrict__ h, const bf16_t* __restrict__ delta,
+                                                      const float* __restrict__ part, int S,
+                                                      const bf16_t* __restrict__ w, bf16_t* __restrict__ y,
+                                                      int T, int d, float eps) {
+  __shared__ float red[4];
+  constexpr int LANES = 64 * WAVES_PER_ROW;
+  const int row = WAVES_PER_ROW == 1 ? blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6) : blockIdx.x;
+  const int lane = WAVES_PER_ROW == 1 ? (threadIdx.x & 63) : threadIdx.x;
   if (row >= T) return;
   const int nchunk = d / 8;
+  const size_t slab = static_cast<size_t>(T) * d;
   bf16_t* hrow = h + static_cast<size_t>(row) * d;
   const bf16_t* drow = delta ? delta + static_cast<size_t>(row) * d : nullptr;
-  bf16x8 v[CH];
+  const float* prow = part ? part + static_cast<size_t>(row) * d : nullptr;
+  bf16x8 v[CH], g[CH];
   float ss = 0.f;
 #pragma unroll
   for (int i = 0; i < CH; ++i) {
-    const int c = lane + i * 64;
+    const int c = lane + i * LANES;
     if (c < nchunk) {
       bf16x8 a = *reinterpret_cast<const bf16x8*>(hrow + c * 8);
-      if (drow) {
+      g[i] = *reinterpret_cast<const bf16x8*>(w + c * 8);
+      if (prow) {
+        f32x4 lo = *reinterpret_cast<const f32x4*>(prow + c * 8);
+        f32x4 hi = *reinterpret_cast<const f32x4*>(prow + c * 8 + 4);
+        for (int sp = 1; sp < S; ++sp) {
+          lo += *reinterpret_cast<const f32x4*>(prow + sp * slab + c * 8);
+          hi += *reinterpret_cast<const f32x4*>(prow + sp * slab + c * 8 + 4);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          a[j] = static_cast<short>(f32_to_bf16(bf16_to_f32(static_cast<bf16_t>(a[j])) +
+                                                bf16_to_f32(f32_to_bf16(lo[j]))));
+          a[j + 4] = static_cast<short>(f32_to_bf16(bf16_to_f32(static_cast<bf16_t>(a[j + 4])) +
+                                                    bf16_to_f32(f32_to_bf16(hi[j]))));
+        }
+        *reinterpret_cast<bf16x8*>(hrow + c * 8) = a;
+      } else if (drow) {
         const bf16x8 b = *reinterpret_cast<const bf16x8*>(drow + c * 8);
 #pragma unroll
         for (int j = 0; j < 8; ++j)
@@ -58,18 +83,22 @@ __global__ void rmsnorm_kernel(bf16_t* __restrict__ h, const bf16_t* __restrict_
     }
   }
   ss = wave_sum(ss);
+  if constexpr (WAVES_PER_ROW > 1) {
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = ss;
+    __syncthreads();
+    ss = red[0] + red[1] + red[2] + red[3];
+  }
   const float scale = rsqrtf(ss / static_cast<float>(d) + eps);
   bf16_t* yrow = y + static_cast<size_t>(row) * d;
 #pragma unroll
   for (int i = 0; i < CH; ++i) {
-    const int c = lane + i * 64;
+    const int c = lane + i * LANES;
     if (c < nchunk) {
-      const bf16x8 g = *reinterpret_cast<const bf16x8*>(w + c * 8);
       bf16x8 o;
 #pragma unroll
       for (int j = 0; j < 8; ++j)
         o[j] = static_cast<short>(f32_to_bf16(bf16_to_f32(static_cast<bf16_t>(v[i][j])) * scale *
-                                              bf16_to_f32(static_cast<bf16_t>(g[j]))));
+                                              bf16_to_f32(static_cast<bf16_t>(g[i][j]))));
       *reinterpret_cast<bf16x8*>(yrow + c * 8) = o;
     }
   }
@@ -162,17 +191,24 @@ LC_EXPORT int lc_embed_gather(const void* ids, const void* E, void* x, int T, in
 }
 
 LC_EXPORT int lc_rmsnorm(void* h, const void* delta, const void* w, void* y, int T, int d, float eps,
-                         hipStream_t stream) {
+                         const void* part, int S, hipStream_t stream) {
   if (T <= 0) return 0;
-  if (d % 8 || d > kMaxChunksPerLane * 64 * 8) return -1;
-  const dim3 grid((T + 3) / 4), block(256);
-#define LC_RMS(CH)                                                                               \
-  rmsnorm_kernel<CH><<<grid, block, 0, stream>>>(static_cast<bf16_t*>(h), static_cast<const bf16_t*>(delta), \
-                                                 static_cast<const bf16_t*>(w), static_cast<bf16_t*>(y), T, d, eps)
-  if (d <= 2 * 512) LC_RMS(2);
-  else if (d <= 4 * 512) LC_RMS(4);
-  else if (d <= 8 * 512) LC_RMS(8);
-  else LC_RMS(16);
+  if (d % 8 || d > kMaxChunksPerLane * 64 * 8 || (part && (S < 1 || delta))) return -1;
+#define LC_RMS(CH, WPR, GRID)                                                                   \
+  rmsnorm_kernel<CH, WPR><<<dim3(GRID), dim3(256), 0, stream>>>(                                 \
+      static_cast<bf16_t*>(h), static_cast<const bf16_t*>(delta), static_cast<const float*>(part), S, \
+      static_cast<const bf16_t*>(w), static_cast<bf16_t*>(y), T, d, eps)
+  if (T <= 1024) {  // few rows: a block per row
+    if (d <= 1 * 2048) LC_RMS(1, 4, T);
+    else if (d <= 2 * 2048) LC_RMS(2, 4, T);
+    else LC_RMS(4, 4, T);
+  } else {
+    const int grid = (T + 3) / 4;
+    if (d <= 2 * 512) LC_RMS(2, 1, grid);
+    else if (d <= 4 * 512) LC_RMS(4, 1, grid);
+    else if (d <= 8 * 512) LC_RMS(8, 1, grid);
+    else LC_RMS(16, 1, grid);
+  }
 #undef LC_RMS
   LC_RETURN_LAST_ERROR();
 }

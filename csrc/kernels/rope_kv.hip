@@ -5,48 +5,93 @@
 // cos/sin come from a host-built fp32 table [max_pos][Dh/2] (on-device trig would make
 // this VALU-bound). Rotation is the "rotate-half" convention of HF Llama/Mistral/Qwen2:
 // pairs (i, i + Dh/2).
+//
+// The projection may arrive un-reduced: `part` = S fp32 slabs [S][T][ld] from a split-K
+// GEMM (+ optional bias). The slabs are summed here, so the separate reduction kernel and
+// its launch disappear from the decode step; Q is then written (rotated, bf16) into `qkv`.
 #include "common.h"
 
 namespace {
 
 template <int DH>
-__global__ void rope_kv_write_kernel(bf16_t* __restrict__ qkv, const int32_t* __restrict__ positions,
-                                     const int32_t* __restrict__ slot_mapping,
-                                     const float* __restrict__ cos_t, const float* __restrict__ sin_t,
-                                     bf16_t* __restrict__ Kc, bf16_t* __restrict__ Vt, int T, int Hq,
-                                     int Hkv, int BS, int max_pos) {
+__global__ __launch_bounds__(256) void rope_kv_write_kernel(
+    bf16_t* __restrict__ qkv, const int32_t* __restrict__ positions, const int32_t* __restrict__ slot_mapping,
+    const float* __restrict__ cos_t, const float* __restrict__ sin_t, bf16_t* __restrict__ Kc,
+    bf16_t* __restrict__ Vt, int T, int Hq, int Hkv, int BS, int max_pos, const float* __restrict__ part, int S,
+    const bf16_t* __restrict__ bias) {
   constexpr int HALF = DH / 2;
+  constexpr int QUADS = HALF / 4;  // work item = 4 consecutive rotation pairs (or 8 V elements)
   const int t = blockIdx.x;
-  const int lane = threadIdx.x & 63;
-  const int wave = threadIdx.x >> 6, nwave = blockDim.x >> 6;
   int pos = positions[t];
   pos = pos < 0 ? 0 : (pos >= max_pos ? max_pos - 1 : pos);
   const int slot = slot_mapping[t];
   const int blk = slot / BS, off = slot % BS;
-  bf16_t* row = qkv + static_cast<size_t>(t) * (Hq + 2 * Hkv) * DH;
   const int nheads = Hq + 2 * Hkv;
-  for (int hd = wave; hd < nheads; hd += nwave) {
-    bf16_t* x = row + hd * DH;
-    if (hd < Hq + Hkv) {
-      // rotate (Q in place; K into the cache)
-      for (int i = lane; i < HALF; i += 64) {
-        const float c = cos_t[static_cast<size_t>(pos) * HALF + i], s = sin_t[static_cast<size_t>(pos) * HALF + i];
-        const float a = bf16_to_f32(x[i]), b = bf16_to_f32(x[i + HALF]);
-        const bf16_t ra = f32_to_bf16(a * c - b * s), rb = f32_to_bf16(b * c + a * s);
-        if (hd < Hq) {
-          x[i] = ra;
-          x[i + HALF] = rb;
-        } else if (slot >= 0) {
-          bf16_t* dst = Kc + ((static_cast<size_t>(blk) * Hkv + (hd - Hq)) * BS + off) * DH;
-          dst[i] = ra;
-          dst[i + HALF] = rb;
-        }
+  const int ld = nheads * DH;
+  const size_t slab = static_cast<size_t>(T) * ld;
+  bf16_t* row = qkv + static_cast<size_t>(t) * ld;
+  const float* prow = part ? part + static_cast<size_t>(t) * ld : nullptr;
+
+  // four consecutive elements of this token's projection row, rounded to bf16 precision
+  // (the rounding point of a bf16 GEMM epilogue) and widened to fp32
+  auto load4 = [&](int col) -> f32x4 {
+    f32x4 v;
+    if (prow) {
+      v = *reinterpret_cast<const f32x4*>(prow + col);
+      for (int sp = 1; sp < S; ++sp) v += *reinterpret_cast<const f32x4*>(prow + sp * slab + col);
+      if (bias) {
+        const u32x2 bb = *reinterpret_cast<const u32x2*>(bias + col);
+        v[0] += bf16_to_f32(static_cast<bf16_t>(bb[0] & 0xffff));
+        v[1] += bf16_to_f32(static_cast<bf16_t>(bb[0] >> 16));
+        v[2] += bf16_to_f32(static_cast<bf16_t>(bb[1] & 0xffff));
+        v[3] += bf16_to_f32(static_cast<bf16_t>(bb[1] >> 16));
       }
-    } else if (slot >= 0) {
-      const int vh = hd - Hq - Hkv;
-      bf16_t* dst = Vt + (static_cast<size_t>(blk) * Hkv + vh) * DH * BS + off;
-      for (int i = lane; i < DH; i += 64) dst[static_cast<size_t>(i) * BS] = x[i];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[j] = bf16_to_f32(f32_to_bf16(v[j]));
+    } else {
+      const u32x2 xx = *reinterpret_cast<const u32x2*>(row + col);
+      v[0] = bf16_to_f32(static_cast<bf16_t>(xx[0] & 0xffff));
+      v[1] = bf16_to_f32(static_cast<bf16_t>(xx[0] >> 16));
+      v[2] = bf16_to_f32(static_cast<bf16_t>(xx[1] & 0xffff));
+      v[3] = bf16_to_f32(static_cast<bf16_t>(xx[1] >> 16));
     }
+    return v;
+  };
+  auto store4 = [](bf16_t* dst, const f32x4& v) {
+    u32x2 o;
+    o[0] = pack_bf16x2(v[0], v[1]);
+    o[1] = pack_bf16x2(v[2], v[3]);
+    *reinterpret_cast<u32x2*>(dst) = o;
+  };
+
+  // ---- Q and K heads: rotate pairs (i, i + HALF) ----
+  const int n_rot = (Hq + Hkv) * QUADS;
+  for (int it = threadIdx.x; it < n_rot; it += blockDim.x) {
+    const int hd = it / QUADS, i = (it % QUADS) * 4;
+    if (hd >= Hq && slot < 0) continue;
+    const f32x4 a = load4(hd * DH + i), b = load4(hd * DH + i + HALF);
+    const f32x4 c = *reinterpret_cast<const f32x4*>(cos_t + static_cast<size_t>(pos) * HALF + i);
+    const f32x4 sn = *reinterpret_cast<const f32x4*>(sin_t + static_cast<size_t>(pos) * HALF + i);
+    f32x4 ra, rb;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      ra[j] = a[j] * c[j] - b[j] * sn[j];
+      rb[j] = b[j] * c[j] + a[j] * sn[j];
+    }
+    bf16_t* dst = hd < Hq ? row + hd * DH
+                          : Kc + ((static_cast<size_t>(blk) * Hkv + (hd - Hq)) * BS + off) * DH;
+    store4(dst + i, ra);
+    store4(dst + i + HALF, rb);
+  }
+  // ---- V heads: transposed scatter ----
+  if (slot < 0) return;
+  const int n_v = Hkv * (DH / 4);
+  for (int it = threadIdx.x; it < n_v; it += blockDim.x) {
+    const int vh = it / (DH / 4), i = (it % (DH / 4)) * 4;
+    const f32x4 v = load4((Hq + Hkv + vh) * DH + i);
+    bf16_t* dst = Vt + ((static_cast<size_t>(blk) * Hkv + vh) * DH + i) * BS + off;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) dst[static_cast<size_t>(j) * BS] = f32_to_bf16(v[j]);
   }
 }
 
@@ -54,15 +99,16 @@ __global__ void rope_kv_write_kernel(bf16_t* __restrict__ qkv, const int32_t* __
 
 LC_EXPORT int lc_rope_kv_write(void* qkv, const void* positions, const void* slot_mapping,
                                const void* cos_t, const void* sin_t, void* Kc, void* Vt, int T, int Hq,
-                               int Hkv, int Dh, int block_size, int max_pos, hipStream_t stream) {
+                               int Hkv, int Dh, int block_size, int max_pos, const void* part, int S,
+                               const void* bias, hipStream_t stream) {
   if (T <= 0) return 0;
-  if (Dh != 64 && Dh != 128) return -1;
+  if ((Dh != 64 && Dh != 128) || (part && S < 1)) return -1;
   const dim3 grid(T), block(256);
 #define LC_ARGS                                                                                       \
   static_cast<bf16_t*>(qkv), static_cast<const int32_t*>(positions),                                  \
       static_cast<const int32_t*>(slot_mapping), static_cast<const float*>(cos_t),                    \
       static_cast<const float*>(sin_t), static_cast<bf16_t*>(Kc), static_cast<bf16_t*>(Vt), T, Hq, Hkv, \
-      block_size, max_pos
+      block_size, max_pos, static_cast<const float*>(part), S, static_cast<const bf16_t*>(bias)
   if (Dh == 128) rope_kv_write_kernel<128><<<grid, block, 0, stream>>>(LC_ARGS);
   else rope_kv_write_kernel<64><<<grid, block, 0, stream>>>(LC_ARGS);
 #undef LC_ARGS

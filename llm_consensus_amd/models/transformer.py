@@ -211,12 +211,13 @@ class TransformerModel:
         c = self.cfg
         h = ops.embed(token_ids, self.embed)
         delta = None
+        defer = self.tp_size == 1   # an all-reduce needs the reduced tensor; the fused norm does not
         for i, L in enumerate(self.layers):
             x = ops.rmsnorm(h, L.ln1, c.rms_eps, delta)
-            qkv = ops.linear(x, L.qkv)
+            qkv = ops.linear(x, L.qkv, defer_reduce=True)
             kc, vc = kv.k(i), kv.vt(i)
-            ops.rope_kv_write(qkv, positions, slot_mapping, self.cos_t, self.sin_t, kc, vc, self.hq, self.hkv,
-                              c.head_dim)
+            qkv = ops.rope_kv_write(qkv, positions, slot_mapping, self.cos_t, self.sin_t, kc, vc, self.hq, self.hkv,
+                                    c.head_dim)
             if meta.is_prefill:
                 a = ops.attn_prefill(qkv, kc, vc, meta.block_tables, meta.cu_q, meta.ctx_lens, meta.max_q_len,
                                      self.hq, self.hkv, c.head_dim, self.scale, c.sliding_window)
@@ -224,7 +225,7 @@ class TransformerModel:
                 a = ops.attn_decode(qkv, kc, vc, meta.block_tables, meta.ctx_lens, self.hq, self.hkv, c.head_dim,
                                     self.scale, c.sliding_window, meta.nsplit, meta.groups, meta.kv_begin,
                                     meta.max_group_rows, meta.prefix_splits)
-            o = self._all_reduce(ops.linear(a, L.o))
+            o = self._all_reduce(ops.linear(a, L.o, defer_reduce=defer))
             x2 = ops.rmsnorm(h, L.ln2, c.rms_eps, o)
             if c.is_moe and self.ep_size > 1:
                 delta = moe_ffn_ep(x2, L.router, L.experts_gate_up, L.experts_down, c.experts_per_tok, self.comm,
@@ -233,7 +234,7 @@ class TransformerModel:
                 delta = self._all_reduce(ops.moe_ffn(x2, L.router, L.experts_gate_up, L.experts_down,
                                                      c.experts_per_tok))
             else:
-                delta = self._all_reduce(ops.linear(ops.linear(x2, L.gate_up), L.down))
+                delta = self._all_reduce(ops.linear(ops.linear(x2, L.gate_up), L.down, defer_reduce=defer))
         return ops.rmsnorm(h, self.final_norm, c.rms_eps, delta)
 
     def logits(self, hidden_rows: torch.Tensor) -> torch.Tensor:

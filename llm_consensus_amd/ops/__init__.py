@@ -130,8 +130,31 @@ def _choose_splits(n_pad: int, K: int, M: int, allow: bool) -> int:
     return best
 
 
-def linear(x: torch.Tensor, w: LinearWeight, out_f32: bool = False) -> torch.Tensor:
-    """y = x @ W^T (+bias). With ``w.swiglu`` returns silu(gate)*up of width N/2."""
+@dataclass
+class PartialSum:
+    """Un-reduced output of a split-K GEMM: ``part`` holds S fp32 slabs [S, M, N] whose sum
+    (+ bias) is the product. Consumers that read the product exactly once (the residual-add
+    RMSNorm, the RoPE/KV-write kernel) sum the slabs themselves, which removes one kernel
+    launch per GEMM from the decode step; anything else calls ``reduce()``."""
+
+    part: torch.Tensor
+    bias: Optional[torch.Tensor] = None
+
+    @property
+    def shape(self):
+        return self.part.shape[1:]
+
+    def reduce(self, out_f32: bool = False) -> torch.Tensor:
+        S, M, N = self.part.shape
+        y = torch.empty(M, N, dtype=torch.float32 if out_f32 else torch.bfloat16, device=self.part.device)
+        _hip().call("lc_splitk_reduce", self.part.data_ptr(), _hip().ptr(self.bias), y.data_ptr(), S, M, N, N,
+                    1 if out_f32 else 0)
+        return y
+
+
+def linear(x: torch.Tensor, w: LinearWeight, out_f32: bool = False, defer_reduce: bool = False):
+    """y = x @ W^T (+bias). With ``w.swiglu`` returns silu(gate)*up of width N/2. With
+    ``defer_reduce`` a split-K product may come back as a ``PartialSum``."""
     M = x.shape[0]
     out_n = w.n // 2 if w.swiglu else w.n
     if not x.is_cuda:
@@ -171,6 +194,8 @@ def linear(x: torch.Tensor, w: LinearWeight, out_f32: bool = False) -> torch.Ten
     part = torch.empty(splits, M, w.n, dtype=torch.float32, device=x.device)
     h.call("lc_wsgemm", w.data.data_ptr(), x.data_ptr(), part.data_ptr(), None, M, w.n, w.k, w.n_pad, w.n, EPI_F32,
            splits)
+    if defer_reduce and not w.swiglu and not out_f32:
+        return PartialSum(part, w.bias)
     mode = 2 if w.swiglu else (1 if out_f32 else 0)
     h.call("lc_splitk_reduce", part.data_ptr(), h.ptr(w.bias), y.data_ptr(), splits, M, w.n, out_n, mode)
     return y
@@ -187,15 +212,21 @@ def embed(ids: torch.Tensor, E: torch.Tensor) -> torch.Tensor:
     return x
 
 
-def rmsnorm(hstate: torch.Tensor, w: torch.Tensor, eps: float, delta: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """y = RMSNorm(hstate [+ delta]) * w. When ``delta`` is given, ``hstate`` (the residual
-    stream) is updated in place to hstate + delta first."""
+def rmsnorm(hstate: torch.Tensor, w: torch.Tensor, eps: float, delta=None) -> torch.Tensor:
+    """y = RMSNorm(hstate [+ delta]) * w. When ``delta`` (a tensor or a ``PartialSum``) is
+    given, ``hstate`` (the residual stream) is updated in place to hstate + delta first."""
     if not hstate.is_cuda:
         return ref.rmsnorm(hstate, w, eps, delta)
     h = _hip()
     T, d = hstate.shape
     y = torch.empty_like(hstate)
-    h.call("lc_rmsnorm", hstate.data_ptr(), h.ptr(delta), w.data_ptr(), y.data_ptr(), T, d, float(eps))
+    if isinstance(delta, PartialSum) and delta.bias is not None:
+        delta = delta.reduce()
+    if isinstance(delta, PartialSum):
+        h.call("lc_rmsnorm", hstate.data_ptr(), None, w.data_ptr(), y.data_ptr(), T, d, float(eps),
+               delta.part.data_ptr(), delta.part.shape[0])
+    else:
+        h.call("lc_rmsnorm", hstate.data_ptr(), h.ptr(delta), w.data_ptr(), y.data_ptr(), T, d, float(eps), None, 0)
     return y
 
 
@@ -229,13 +260,25 @@ def embed_pool(hidden: torch.Tensor, cu: torch.Tensor, mode: int = 0) -> torch.T
 
 
 # ---------------------------------------------------------------------------- rope + cache
-def rope_kv_write(qkv, positions, slot_mapping, cos_t, sin_t, k_cache, vt_cache, Hq, Hkv, Dh) -> None:
+def rope_kv_write(qkv, positions, slot_mapping, cos_t, sin_t, k_cache, vt_cache, Hq, Hkv, Dh) -> torch.Tensor:
+    """Rotates Q in place and writes rotated K / V into the paged cache. ``qkv`` may be a
+    ``PartialSum``; returns the bf16 [T, (Hq+2Hkv)*Dh] buffer whose Q section attention reads."""
+    if isinstance(qkv, PartialSum):
+        h = _hip()
+        S, T, N = qkv.part.shape
+        out = torch.empty(T, N, dtype=torch.bfloat16, device=qkv.part.device)
+        h.call("lc_rope_kv_write", out.data_ptr(), positions.data_ptr(), slot_mapping.data_ptr(), cos_t.data_ptr(),
+               sin_t.data_ptr(), k_cache.data_ptr(), vt_cache.data_ptr(), T, Hq, Hkv, Dh, k_cache.shape[2],
+               cos_t.shape[0], qkv.part.data_ptr(), S, h.ptr(qkv.bias))
+        return out
     if not qkv.is_cuda:
-        return ref.rope_kv_write(qkv, positions, slot_mapping, cos_t, sin_t, k_cache, vt_cache, Hq, Hkv, Dh)
+        ref.rope_kv_write(qkv, positions, slot_mapping, cos_t, sin_t, k_cache, vt_cache, Hq, Hkv, Dh)
+        return qkv
     h = _hip()
     h.call("lc_rope_kv_write", qkv.data_ptr(), positions.data_ptr(), slot_mapping.data_ptr(), cos_t.data_ptr(),
            sin_t.data_ptr(), k_cache.data_ptr(), vt_cache.data_ptr(), qkv.shape[0], Hq, Hkv, Dh, k_cache.shape[2],
-           cos_t.shape[0])
+           cos_t.shape[0], None, 0, None)
+    return qkv
 
 
 def copy_blocks(kv_base: torch.Tensor, src: torch.Tensor, dst: torch.Tensor, block_elems: int, n_planes: int,
@@ -290,10 +333,14 @@ def attn_decode(qkv, k_cache, vt_cache, block_tables, ctx_lens, Hq, Hkv, Dh, sca
     h = _hip()
     out = torch.empty(B, Hq * Dh, dtype=qkv.dtype, device=qkv.device)
     use_prefix = groups is not None and max_group_rows > 1
+    # Up to four of the requested KV splits are taken by the waves of one workgroup, which
+    # merges them on chip; only the remaining factor produces partial slots in HBM.
+    waves = (4 if nsplit >= 4 else (2 if nsplit >= 2 else 1)) if Hq // Hkv <= 8 else 1
+    nsplit = max(1, nsplit // waves)
     if nsplit == 1 and not use_prefix:
         h.call("lc_attn_decode", qkv.data_ptr(), qkv.stride(0), k_cache.data_ptr(), vt_cache.data_ptr(),
                block_tables.data_ptr(), block_tables.shape[1], ctx_lens.data_ptr(), None, out.data_ptr(), None, None,
-               1, 1, B, Hq, Hkv, Dh, k_cache.shape[2], float(scale), int(window))
+               1, 1, B, Hq, Hkv, Dh, k_cache.shape[2], float(scale), int(window), waves)
         return out
     np_total = nsplit + (prefix_splits if use_prefix else 0)
     part_o = torch.empty(B, Hq, np_total, Dh, dtype=torch.float32, device=qkv.device)
@@ -303,7 +350,7 @@ def attn_decode(qkv, k_cache, vt_cache, block_tables, ctx_lens, Hq, Hkv, Dh, sca
     h.call("lc_attn_decode", qkv.data_ptr(), qkv.stride(0), k_cache.data_ptr(), vt_cache.data_ptr(),
            block_tables.data_ptr(), block_tables.shape[1], ctx_lens.data_ptr(),
            kv_begin.data_ptr() if (use_prefix and kv_begin is not None) else None, out.data_ptr(), part_o.data_ptr(),
-           part_lse.data_ptr(), np_total, nsplit, B, Hq, Hkv, Dh, k_cache.shape[2], float(scale), int(window))
+           part_lse.data_ptr(), np_total, nsplit, B, Hq, Hkv, Dh, k_cache.shape[2], float(scale), int(window), waves)
     if use_prefix:
         gf, gc, gs = groups
         h.call("lc_attn_prefix", qkv.data_ptr(), qkv.stride(0), k_cache.data_ptr(), vt_cache.data_ptr(),

@@ -18,7 +18,7 @@ _P, _I, _F, _L = c_void_p, c_int, c_float, c_longlong
 
 _SIGNATURES = {
     "lc_embed_gather": [_P, _P, _P, _I, _I, _I, _P],
-    "lc_rmsnorm": [_P, _P, _P, _P, _I, _I, _F, _P],
+    "lc_rmsnorm": [_P, _P, _P, _P, _I, _I, _F, _P, _I, _P],
     "lc_swiglu": [_P, _P, _I, _I, _P],
     "lc_add": [_P, _P, _P, _L, _P],
     "lc_copy_blocks": [_P, _P, _P, _I, _L, _L, _I, _P],
@@ -29,9 +29,9 @@ _SIGNATURES = {
     "lc_kgemm": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
     "lc_splitk_reduce": [_P, _P, _P, _I, _I, _I, _I, _I, _P],
     "lc_gemm_grouped": [_P, _L, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _P],
-    "lc_rope_kv_write": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
+    "lc_rope_kv_write": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _I, _P, _P],
     "lc_attn_prefill": [_P, _I, _P, _P, _P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _F, _I, _P],
-    "lc_attn_decode": [_P, _I, _P, _P, _P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _F, _I, _P],
+    "lc_attn_decode": [_P, _I, _P, _P, _P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _F, _I, _I, _P],
     "lc_attn_prefix": [_P, _I, _P, _P, _P, _I, _P, _P, _P, _I, _I, _I, _P, _P, _I, _I, _I, _I, _I, _I, _F, _P],
     "lc_attn_merge": [_P, _P, _P, _I, _I, _I, _P],
     "lc_fill_f32": [_P, _F, _L, _P],

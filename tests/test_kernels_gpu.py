@@ -517,3 +517,41 @@ def test_answer_extract_matches_host():
         dev = reducers.answer_extract(ids, lens, mk, choices, win, device=DEV)
         assert np.array_equal(host, dev), (mk, win)
     assert (host >= 0).any() and (host < 0).any()
+
+
+# ------------------------------------------------------------------ deferred split-K reduction
+@pytest.mark.parametrize("T,d,S", [(1, 896, 2), (64, 4096, 4), (256, 3584, 3), (1500, 4096, 2)])
+def test_rmsnorm_sums_splitk_partials(T, d, S):
+    part = rand(S, T, d, scale=0.5, seed=3).to(DEV)
+    hst = bf(rand(T, d, seed=4)).to(DEV)
+    w = bf(1 + 0.1 * rand(d, seed=5)).to(DEV)
+    want_h = hst.clone()
+    delta = part.sum(0).to(torch.bfloat16)
+    want_y = ops.rmsnorm(want_h, w, 1e-5, delta)
+    got_h = hst.clone()
+    got_y = ops.rmsnorm(got_h, w, 1e-5, ops.PartialSum(part))
+    assert rel_err(got_h.float(), want_h.float()) < 1e-2
+    assert rel_err(got_y.float(), want_y.float()) < 1e-2
+    # and against the fp32 oracle
+    href = hst.float().cpu() + part.sum(0).cpu()
+    yref = href * torch.rsqrt((href ** 2).mean(-1, keepdim=True) + 1e-5) * w.float().cpu()
+    assert rel_err(got_y.float().cpu(), yref) < 2e-2
+
+
+@pytest.mark.parametrize("Dh,with_bias", [(128, False), (64, True)])
+def test_rope_kv_write_sums_splitk_partials(Dh, with_bias):
+    T, Hq, Hkv, BS, S = 37, 8, 2, 16, 3
+    N = (Hq + 2 * Hkv) * Dh
+    part = rand(S, T, N, scale=0.5, seed=6).to(DEV)
+    bias = bf(rand(N, seed=7)).to(DEV) if with_bias else None
+    cos, sin = ref.rope_tables(Dh, 256, 1e4)
+    cos, sin = cos.to(DEV), sin.to(DEV)
+    pos = torch.arange(T, dtype=torch.int32, device=DEV) + 3
+    slots = torch.randperm(8 * BS)[:T].to(torch.int32).to(DEV)
+    ps = ops.PartialSum(part, bias)
+    k1, v1 = torch.zeros(8, Hkv, BS, Dh, dtype=torch.bfloat16, device=DEV), torch.zeros(8, Hkv, Dh, BS, dtype=torch.bfloat16, device=DEV)
+    k2, v2 = torch.zeros_like(k1), torch.zeros_like(v1)
+    q1 = ops.rope_kv_write(ps.reduce(), pos, slots, cos, sin, k1, v1, Hq, Hkv, Dh)
+    q2 = ops.rope_kv_write(ps, pos, slots, cos, sin, k2, v2, Hq, Hkv, Dh)
+    assert torch.equal(k1, k2) and torch.equal(v1, v2)
+    assert torch.equal(q1[:, : Hq * Dh], q2[:, : Hq * Dh])
