@@ -65,8 +65,11 @@ __global__ __launch_bounds__(256) void rope_kv_write_kernel(
   };
 
   // ---- Q and K heads: rotate pairs (i, i + HALF) ----
+  // gridDim.y blocks share a token: decode steps have few tokens, and one block per token
+  // would leave most CUs idle while every thread walks a dozen dependent load chains
+  const int tid = blockIdx.y * blockDim.x + threadIdx.x, nthr = gridDim.y * blockDim.x;
   const int n_rot = (Hq + Hkv) * QUADS;
-  for (int it = threadIdx.x; it < n_rot; it += blockDim.x) {
+  for (int it = tid; it < n_rot; it += nthr) {
     const int hd = it / QUADS, i = (it % QUADS) * 4;
     if (hd >= Hq && slot < 0) continue;
     const f32x4 a = load4(hd * DH + i), b = load4(hd * DH + i + HALF);
@@ -86,7 +89,7 @@ __global__ __launch_bounds__(256) void rope_kv_write_kernel(
   // ---- V heads: transposed scatter ----
   if (slot < 0) return;
   const int n_v = Hkv * (DH / 4);
-  for (int it = threadIdx.x; it < n_v; it += blockDim.x) {
+  for (int it = tid; it < n_v; it += nthr) {
     const int vh = it / (DH / 4), i = (it % (DH / 4)) * 4;
     const f32x4 v = load4((Hq + Hkv + vh) * DH + i);
     bf16_t* dst = Vt + ((static_cast<size_t>(blk) * Hkv + vh) * DH + i) * BS + off;
@@ -103,7 +106,7 @@ LC_EXPORT int lc_rope_kv_write(void* qkv, const void* positions, const void* slo
                                const void* bias, hipStream_t stream) {
   if (T <= 0) return 0;
   if ((Dh != 64 && Dh != 128) || (part && S < 1)) return -1;
-  const dim3 grid(T), block(256);
+  const dim3 grid(T, T <= 512 ? 4 : 1), block(256);
 #define LC_ARGS                                                                                       \
   static_cast<bf16_t*>(qkv), static_cast<const int32_t*>(positions),                                  \
       static_cast<const int32_t*>(slot_mapping), static_cast<const float*>(cos_t),                    \

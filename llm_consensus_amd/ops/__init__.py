@@ -24,7 +24,8 @@ WS_MAX_M = int(os.environ.get("LC_WS_MAX_M", "256"))
 GEMM256_MIN_TILES = int(os.environ.get("LC_GEMM256_MIN_TILES", "192"))
 # In-workgroup K-split decode kernel (kgemm.hip): widest output it is used for, and a test override
 # (-1 = automatic, 0 = never, 1/2/4 = force that many n-tiles per workgroup).
-KGEMM_MAX_N = int(os.environ.get("LC_KGEMM_MAX_N", "8192"))
+GEMM256_SKINNY_MIN_TILES = int(os.environ.get("LC_GEMM256_SKINNY_MIN_TILES", "96"))
+KGEMM_MAX_N =int(os.environ.get("LC_KGEMM_MAX_N", "8192"))
 KGEMM_MAX_M = int(os.environ.get("LC_KGEMM_MAX_M", "16"))   # measured: beyond 16 rows the weight-streaming kernel wins
 KGEMM_FORCE_NTW = int(os.environ.get("LC_KGEMM_NTW", "-1"))
 # Target number of workgroups for the weight-streaming kernel (256 CUs on MI355X).
@@ -171,6 +172,15 @@ def linear(x: torch.Tensor, w: LinearWeight, out_f32: bool = False, defer_reduce
     epi = EPI_SWIGLU if w.swiglu else (EPI_F32 if out_f32 else EPI_BF16)
     y = torch.empty(M, out_n, dtype=torch.float32 if (out_f32 and not w.swiglu) else torch.bfloat16, device=x.device)
     if M == 0:
+        return y
+    # 193..256 rows against a wide matrix (gate/up projections): one 256-row tile per 256
+    # columns already keeps >= 96 CUs on the MFMA-dense kernel, which beats streaming the
+    # weights past 16 m-tiles held in LDS (measured 105 vs 138 us at N=28672, K=4096).
+    wide_skinny = 192 < M <= WS_MAX_M and GEMM256_MIN_TILES >= 0 and w.n_pad % 256 == 0 and \
+        w.n_pad // 256 >= GEMM256_SKINNY_MIN_TILES
+    if wide_skinny:
+        h.call("lc_gemm256", w.data.data_ptr(), x.data_ptr(), y.data_ptr(), h.ptr(w.bias), M, w.n, w.k, w.n_pad,
+               out_n, epi)
         return y
     if M > WS_MAX_M:
         tiles256 = ((M + 255) // 256) * (w.n_pad // 256)
