@@ -242,6 +242,10 @@ __global__ __launch_bounds__(64) void attn_decode_kernel(const bf16_t* __restric
     const size_t slot = (static_cast<size_t>(b) * Hq + head) * np_total + split;
     finish_and_store<DH>(st, nullptr, valid ? part_o + slot * DH : nullptr, valid ? part_lse + slot : nullptr,
                          lane);
+    // Rows outside every shared-prefix group get no prefix partials: mark those slots empty
+    // here (the prefix kernel never visits such rows).
+    if (kv_begin && kv_begin[b] == 0 && split == 0 && valid && lane < 32)
+      for (int p = nsplit; p < np_total; ++p) part_lse[slot - split + p] = kNegBig;
   } else {
     finish_and_store<DH>(st, valid ? out + static_cast<size_t>(b) * (Hq * DH) + head * DH : nullptr, nullptr,
                          nullptr, lane);
@@ -315,7 +319,11 @@ __global__ __launch_bounds__(64 * NW) void attn_decode_mw_kernel(
     if (part_o) {
       const size_t slot = (static_cast<size_t>(b) * Hq + hd) * np_total + split;
       part_o[slot * DH + d] = val;
-      if (d == 0) part_lse[slot] = den > 0.f ? mx + log2f(den) : kNegBig;
+      if (d == 0) {
+        part_lse[slot] = den > 0.f ? mx + log2f(den) : kNegBig;
+        if (kv_begin && kv_begin[b] == 0 && split == 0)   // no prefix partials for this row
+          for (int p = nsplit; p < np_total; ++p) part_lse[slot + p] = kNegBig;
+      }
     } else {
       out[static_cast<size_t>(b) * (Hq * DH) + hd * DH + d] = f32_to_bf16(val);
     }

@@ -96,7 +96,10 @@ class _DecodeGraph:
         self.h["slot_mapping"][:] = -1
         self.h["top_p"][:] = 1.0
         self.nsplit = ops.choose_kv_splits(bucket, eng.model.hkv, eng.nominal_ctx)
-        self.prefix_splits = max(1, min(8, 1024 // max(1, self.gmax * eng.model.hkv)))
+        # The shared-prefix pass scans each group's prompt once per kv head; a block that walks
+        # the whole prompt alone is a chain of dependent loads, so the prompt is cut into ~128-key
+        # pieces. Blocks of the (statically sized) group slots that are empty at run time exit at once.
+        self.prefix_splits = max(1, min(8, eng.nominal_ctx // 128))
         self.graph: Optional[torch.cuda.CUDAGraph] = None
         self.out_tokens = self.out_lps = self.out_dec = None
 
@@ -370,7 +373,8 @@ class Engine:
             if ng > g.gmax:
                 raise RuntimeError("more sequence groups than the decode graph was sized for")
             put("group_first", plan.group_first)
-            put("group_count", np.where(gshared > 0, gcount, 0).astype(np.int32))
+            # only groups the per-row pass skips the prefix for (kv_begin > 0 below) may run the prefix pass
+            put("group_count", np.where((gshared > 0) & (gcount > 1), gcount, 0).astype(np.int32))
             put("group_shared", gshared)
             kvb = np.zeros(B, np.int32)
             for gi in range(ng):

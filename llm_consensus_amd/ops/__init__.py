@@ -22,10 +22,11 @@ WS_MAX_M = int(os.environ.get("LC_WS_MAX_M", "256"))
 # The 256x256 pipelined kernel runs one workgroup per CU: use it once a launch has at least this
 # many 256x256 tiles (fewer tiles leave CUs idle; the 128x128 kernel fills the chip better). -1 disables.
 GEMM256_MIN_TILES = int(os.environ.get("LC_GEMM256_MIN_TILES", "192"))
+# ... and for 193-256 rows already from this many 256-column tiles (see linear()).
+GEMM256_SKINNY_MIN_TILES = int(os.environ.get("LC_GEMM256_SKINNY_MIN_TILES", "96"))
 # In-workgroup K-split decode kernel (kgemm.hip): widest output it is used for, and a test override
 # (-1 = automatic, 0 = never, 1/2/4 = force that many n-tiles per workgroup).
-GEMM256_SKINNY_MIN_TILES = int(os.environ.get("LC_GEMM256_SKINNY_MIN_TILES", "96"))
-KGEMM_MAX_N =int(os.environ.get("LC_KGEMM_MAX_N", "8192"))
+KGEMM_MAX_N = int(os.environ.get("LC_KGEMM_MAX_N", "8192"))
 KGEMM_MAX_M = int(os.environ.get("LC_KGEMM_MAX_M", "16"))   # measured: beyond 16 rows the weight-streaming kernel wins
 KGEMM_FORCE_NTW = int(os.environ.get("LC_KGEMM_NTW", "-1"))
 # Target number of workgroups for the weight-streaming kernel (256 CUs on MI355X).
@@ -355,8 +356,6 @@ def attn_decode(qkv, k_cache, vt_cache, block_tables, ctx_lens, Hq, Hkv, Dh, sca
     np_total = nsplit + (prefix_splits if use_prefix else 0)
     part_o = torch.empty(B, Hq, np_total, Dh, dtype=torch.float32, device=qkv.device)
     part_lse = torch.empty(B, Hq, np_total, dtype=torch.float32, device=qkv.device)
-    if use_prefix:
-        h.call("lc_fill_f32", part_lse.data_ptr(), -1.0e30, part_lse.numel())
     h.call("lc_attn_decode", qkv.data_ptr(), qkv.stride(0), k_cache.data_ptr(), vt_cache.data_ptr(),
            block_tables.data_ptr(), block_tables.shape[1], ctx_lens.data_ptr(),
            kv_begin.data_ptr() if (use_prefix and kv_begin is not None) else None, out.data_ptr(), part_o.data_ptr(),
