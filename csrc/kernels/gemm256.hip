@@ -2,8 +2,9 @@
 // stays in flight across barriers (counted s_waitcnt vmcnt, raw s_barrier).
 //
 // Same operand conventions as gemm.hip: packed weights (MFMA-fragment order) are the
-// MFMA A operand, activations the B operand, both staged with global_load_lds_dwordx4
-// into a lane-linear LDS image (conflict-free ds_read_b128).
+// MFMA A operand, activations the B operand, both staged with global_load_lds_dwordx4:
+// weights as ready-made fragments (lane-linear image, conflict-free ds_read_b128),
+// activations as whole 128-byte rows in an XOR-swizzled image.
 //
 // Work split. Wave (wn = w&3, wm = w>>2) owns 64 n x 128 m of the tile = 4 x 8
 // accumulator fragments (128 VGPRs). A K-tile (64 deep) is consumed in four phases of
@@ -51,13 +52,25 @@ LC_DEVICE void g2_issue_half(const G2Ctx& c, int k_tile, int which) {
     __builtin_amdgcn_global_load_lds(LC_GLOBAL_PTR(src), LC_LDS_PTR(dst), 16, 0, 0);
     __builtin_amdgcn_global_load_lds(LC_GLOBAL_PTR(src + 512), LC_LDS_PTR(dst + 1024), 16, 0, 0);
   } else {
-    int row = c.m0 + tile * 16 + (c.lane & 15);
-    row = row < c.M ? row : c.M - 1;
-    const bf16_t* src = c.X + static_cast<size_t>(row) * c.K + kt0 * 32 + 8 * (c.lane >> 4);
+    // Two pieces of 8 rows x 128 B (whole cache lines: the K-tile's full width). The LDS image
+    // of a DMA is lane-linear, so the XOR swizzle that spreads the fragment reads over the banks
+    // is applied on the source side: lane (rr = l>>3, lc = l&7) fetches 16-byte chunk lc^rr of
+    // row rr; chunk c of row rr is then read at position c^rr (g2_x_off).
+    const int rr = c.lane >> 3, lc = c.lane & 7;
+    int row0 = c.m0 + tile * 16 + rr, row1 = row0 + 8;
+    row0 = row0 < c.M ? row0 : c.M - 1;
+    row1 = row1 < c.M ? row1 : c.M - 1;
+    const int koff = kt0 * 32 + ((lc ^ rr) << 3);
     char* dst = stage + G2_XOFF + (tile * 2) * 1024;
-    __builtin_amdgcn_global_load_lds(LC_GLOBAL_PTR(src), LC_LDS_PTR(dst), 16, 0, 0);
-    __builtin_amdgcn_global_load_lds(LC_GLOBAL_PTR(src + 32), LC_LDS_PTR(dst + 1024), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds(LC_GLOBAL_PTR(c.X + static_cast<size_t>(row0) * c.K + koff), LC_LDS_PTR(dst), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds(LC_GLOBAL_PTR(c.X + static_cast<size_t>(row1) * c.K + koff), LC_LDS_PTR(dst + 1024), 16, 0, 0);
   }
+}
+
+// Byte offset, inside one m-tile's 2-KiB image, of this lane's B fragment for k-tile kt.
+LC_DEVICE int g2_x_off(int kt, int lane) {
+  const int r = lane & 15, rr = r & 7;
+  return (r >> 3) * 1024 + rr * 128 + (((kt * 4 + (lane >> 4)) ^ rr) << 4);
 }
 
 #define G2_MFMA_QUADRANT(NLO, BFR, MLO)                                                              \
@@ -108,6 +121,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const bf16_t* __restrict__
 #pragma unroll
     for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   bf16x8 a[4][2], b0[4][2], b1[4][2];
+  const int xoff[2] = {g2_x_off(0, lane), g2_x_off(1, lane)};
 
   // ---- prologue: K-tile 0 completely, plus the three halves of K-tile 1 that steady state
   //      expects to be in flight at the top of a K-tile ----
@@ -126,7 +140,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const bf16_t* __restrict__
 
   for (int t = 0; t < c.nk; ++t) {
     const char* wimg = smem + (t & 1) * G2_STAGE + (wn * 4 * 2) * 1024 + lane * 16;
-    const char* ximg = smem + (t & 1) * G2_STAGE + G2_XOFF + (wm * 8 * 2) * 1024 + lane * 16;
+    const char* ximg = smem + (t & 1) * G2_STAGE + G2_XOFF + (wm * 8 * 2) * 1024;
     // ---------------- P1 ----------------
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -135,7 +149,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const bf16_t* __restrict__
 #pragma unroll
     for (int j = 0; j < 4; ++j)
 #pragma unroll
-      for (int kt = 0; kt < 2; ++kt) b0[j][kt] = *reinterpret_cast<const bf16x8*>(ximg + (j * 2 + kt) * 1024);
+      for (int kt = 0; kt < 2; ++kt) b0[j][kt] = *reinterpret_cast<const bf16x8*>(ximg + j * 2048 + xoff[kt]);
     g2_issue_half(c, t + 1, 3);
     // Reads are retired BEFORE the barrier: the W regions are re-staged by the other wave
     // group in the very next slot.
@@ -148,7 +162,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const bf16_t* __restrict__
     for (int j = 0; j < 4; ++j)
 #pragma unroll
       for (int kt = 0; kt < 2; ++kt)
-        b1[j][kt] = *reinterpret_cast<const bf16x8*>(ximg + ((4 + j) * 2 + kt) * 1024);
+        b1[j][kt] = *reinterpret_cast<const bf16x8*>(ximg + (4 + j) * 2048 + xoff[kt]);
     g2_issue_half(c, t + 2, 0);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     G2_BARRIER();

@@ -22,8 +22,10 @@ WS_MAX_M = int(os.environ.get("LC_WS_MAX_M", "256"))
 # The 256x256 pipelined kernel runs one workgroup per CU: use it once a launch has at least this
 # many 256x256 tiles (fewer tiles leave CUs idle; the 128x128 kernel fills the chip better). -1 disables.
 GEMM256_MIN_TILES = int(os.environ.get("LC_GEMM256_MIN_TILES", "192"))
-# ... and for 193-256 rows already from this many 256-column tiles (see linear()).
-GEMM256_SKINNY_MIN_TILES = int(os.environ.get("LC_GEMM256_SKINNY_MIN_TILES", "96"))
+# Single-panel kernel (gemm_m256.hip): used for M_PANEL_MIN_M < M <= 256 once there are this many
+# 128-column tiles (a large value disables it).
+M_PANEL_MIN_M = int(os.environ.get("LC_M_PANEL_MIN_M", "128"))
+M_PANEL_MIN_TILES = int(os.environ.get("LC_M_PANEL_MIN_TILES", "160"))
 # In-workgroup K-split decode kernel (kgemm.hip): widest output it is used for, and a test override
 # (-1 = automatic, 0 = never, 1/2/4 = force that many n-tiles per workgroup).
 KGEMM_MAX_N = int(os.environ.get("LC_KGEMM_MAX_N", "8192"))
@@ -174,14 +176,13 @@ def linear(x: torch.Tensor, w: LinearWeight, out_f32: bool = False, defer_reduce
     y = torch.empty(M, out_n, dtype=torch.float32 if (out_f32 and not w.swiglu) else torch.bfloat16, device=x.device)
     if M == 0:
         return y
-    # 193..256 rows against a wide matrix (gate/up projections): one 256-row tile per 256
-    # columns already keeps >= 96 CUs on the MFMA-dense kernel, which beats streaming the
-    # weights past 16 m-tiles held in LDS (measured 105 vs 138 us at N=28672, K=4096).
-    wide_skinny = 192 < M <= WS_MAX_M and GEMM256_MIN_TILES >= 0 and w.n_pad % 256 == 0 and \
-        w.n_pad // 256 >= GEMM256_SKINNY_MIN_TILES
-    if wide_skinny:
-        h.call("lc_gemm256", w.data.data_ptr(), x.data_ptr(), y.data_ptr(), h.ptr(w.bias), M, w.n, w.k, w.n_pad,
-               out_n, epi)
+    # 129..256 rows against a wide matrix (gate/up and vocabulary projections of a K-chain decode
+    # step): the 128x256 single-panel kernel gives every CU one MFMA-dense tile; streaming the
+    # weights past 16 m-tiles held in LDS is LDS-bound there (measured at N=28672, K=4096, M=256).
+    # Past 256 such tiles a second round would start; 256x256 tiles (half as many) are better then.
+    if M_PANEL_MIN_M < M <= 256 and w.n_pad // 128 >= M_PANEL_MIN_TILES and w.k >= 128:
+        kernel = "lc_gemm256" if (w.n_pad // 128 > 256 and w.n_pad % 256 == 0) else "lc_gemm_m256"
+        h.call(kernel, w.data.data_ptr(), x.data_ptr(), y.data_ptr(), h.ptr(w.bias), M, w.n, w.k, w.n_pad, out_n, epi)
         return y
     if M > WS_MAX_M:
         tiles256 = ((M + 255) // 256) * (w.n_pad // 256)
