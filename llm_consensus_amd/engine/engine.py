@@ -10,6 +10,7 @@ moves small int32 arrays per step; tokens are sampled on device.
 from __future__ import annotations
 
 import contextlib
+import os
 import time
 from dataclasses import dataclass, field
 from typing import Dict, List, Optional, Sequence
@@ -163,7 +164,13 @@ class Engine:
         self.nominal_ctx = min(self.max_model_len, 1024)
         self.max_decision = max_decision
         self.max_group_rows = max_group_rows
-        self.use_graphs = (self.device.type == "cuda") if use_graphs is None else (use_graphs and self.device.type == "cuda")
+        # Decode steps are captured into hipGraphs by default. Steps that contain collectives
+        # (tensor / expert parallel members) run eagerly unless asked otherwise: capturing RCCL
+        # calls needs every rank of the group to capture and replay in lock step.
+        sharded = model.tp_size > 1 or model.ep_size > 1
+        if use_graphs is None:
+            use_graphs = not sharded or os.environ.get("CONSENSUS_GRAPH_COLLECTIVES", "0") == "1"
+        self.use_graphs = bool(use_graphs) and self.device.type == "cuda"
         self.graph_buckets = sorted(b for b in graph_buckets if b <= max_batch_seqs) or [max_batch_seqs]
         self.graph_pool = None
         # Every engine issues its GPU work on a stream of its own, so the engines of one
