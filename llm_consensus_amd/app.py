@@ -9,7 +9,8 @@ come from configuration; with no configuration the result is the reference's top
 """
 from __future__ import annotations
 
-from dataclasses import dataclass
+import time
+from dataclasses import dataclass, field
 from typing import Dict, List, Optional
 
 import torch
@@ -27,6 +28,7 @@ from .models.loader import build_model
 from .parallel.placement import plan_for_config
 from .utils.log import get_logger
 from .utils.tokenizer import make_tokenizer
+from .utils.trace import instant, span
 
 log = get_logger("consensus.app")
 
@@ -39,14 +41,53 @@ class Ensemble:
     strategy: object
     device: torch.device
 
+    metrics: "core.Metrics" = field(default_factory=core.Metrics)
+
     def ask(self, question: str):
-        return self.strategy.ask(question)
+        return self.ask_many([question])[0]
 
     def ask_many(self, questions):
-        return self.strategy.ask_many(list(questions))
+        """Answers a batch and records the ensemble-level counters: answers, batches, wall
+        time, rounds per question, member calls, agreement, unanimity, per-question latency.
+        The reference counts nothing (its only timer paces a poll loop, main.rs:449-454)."""
+        qs = list(questions)
+        t0 = time.perf_counter()
+        with span("ask_many", "ensemble", questions=len(qs), strategy=self.config.strategy):
+            results = self.strategy.ask_many(qs)
+        dt = time.perf_counter() - t0
+        m = self.metrics
+        m.inc("answers", len(results))
+        m.inc("batches")
+        m.inc("seconds", dt)
+        for r in results:
+            m.observe("latency_ms", r.latency_s * 1e3)
+            m.observe("rounds", r.rounds)
+            m.observe("agreement", r.agreement)
+            m.inc("member_calls", r.member_calls)
+            m.inc("unanimous", 1 if r.unanimous else 0)
+            m.inc("forced", 1 if getattr(r, "forced", False) else 0)
+            instant("session.done", "ensemble", rounds=r.rounds, calls=r.member_calls, unanimous=r.unanimous,
+                    latency_ms=round(r.latency_s * 1e3, 2))
+        return results
 
     def stats(self) -> Dict[str, Dict[str, float]]:
-        return {name: b.stats() for name, b in self.backends.items()}
+        """Per-model engine statistics plus a ``consensus`` section (answers/s, latency
+        percentiles, rounds, agreement) and a ``device`` section (HBM use)."""
+        out: Dict[str, Dict[str, float]] = {name: b.stats() for name, b in self.backends.items()}
+        c = dict(self.metrics.snapshot())
+        if c.get("seconds", 0) > 0:
+            c["answers_per_s"] = c.get("answers", 0) / c["seconds"]
+        if c.get("answers", 0) > 0:
+            c["unanimous_rate"] = c.get("unanimous", 0) / c["answers"]
+        for name, st in out.items():
+            if st.get("decode.seconds", 0) > 0:
+                c[f"decode_tokens_per_s.{name}"] = st.get("decode.tokens", 0) / st["decode.seconds"]
+        out["consensus"] = c
+        if self.device.type == "cuda":
+            free, total = torch.cuda.mem_get_info(self.device)
+            out["device"] = {"hbm_total_bytes": float(total), "hbm_used_bytes": float(total - free),
+                             "hbm_allocated_bytes": float(torch.cuda.memory_allocated(self.device))}
+        return out
 
 
 def default_device() -> torch.device:

@@ -28,6 +28,10 @@ log = get_logger("consensus.engine")
 PK = core.StepPlan.Kind
 
 
+def serialize_streams() -> bool:
+    return os.environ.get("CONSENSUS_SERIALIZE_STREAMS", "0") == "1"
+
+
 @dataclass
 class RequestOutput:
     request_id: int
@@ -175,7 +179,10 @@ class Engine:
         self.graph_pool = None
         # Every engine issues its GPU work on a stream of its own, so the engines of one
         # ensemble can have steps in flight at the same time (see run_engines).
-        self.stream = torch.cuda.Stream(device=self.device) if self.device.type == "cuda" else None
+        # CONSENSUS_SERIALIZE_STREAMS=1 is the debug mode for stream-order bugs: everything runs
+        # on the default stream, one engine at a time, and results must not change.
+        own_stream = self.device.type == "cuda" and not serialize_streams()
+        self.stream = torch.cuda.Stream(device=self.device) if own_stream else None
         if self.stream is not None:
             self.stream.wait_stream(torch.cuda.current_stream(self.device))   # weights were written there
         self._graphs: Dict[tuple, _DecodeGraph] = {}
@@ -456,7 +463,7 @@ def run_engines(engines: Sequence["Engine"]) -> None:
     dominated by short kernels whose launch ramps and end-of-kernel cache write-backs leave
     CUs idle; kernels of the other members fill those gaps."""
     live = [e for e in engines if e.has_work()]
-    if len(live) <= 1:
+    if len(live) <= 1 or serialize_streams():
         for e in live:
             e.run_until_done()
         return

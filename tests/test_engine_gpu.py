@@ -163,3 +163,37 @@ def test_strategies_end_to_end_on_gpu_backend():
     assert all(1 <= r.rounds <= 5 and r.answer for r in out)
     st = backends[0].stats()
     assert st["kv.prefix_hit_rate"] > 0.2          # evaluate prompts share their question/answer prefix
+
+
+def test_overlapped_engines_match_serialized_streams(monkeypatch):
+    """Stream-order debug mode: with CONSENSUS_SERIALIZE_STREAMS=1 every engine runs on the
+    default stream, one after the other; the overlapped multi-stream run must give the same
+    tokens and decision log-probs."""
+    from llm_consensus_amd.engine.engine import run_engines
+
+    cfgs = [("tiny-llama", 3), ("tiny-qwen", 4), ("small-llama", 5)]
+    rng = np.random.default_rng(1)
+    prompts = [rng.integers(0, 500, size=int(n)).tolist() for n in (40, 7, 90, 33, 64, 12)]
+
+    def run(serialized):
+        if serialized:
+            monkeypatch.setenv("CONSENSUS_SERIALIZE_STREAMS", "1")
+        else:
+            monkeypatch.delenv("CONSENSUS_SERIALIZE_STREAMS", raising=False)
+        engines, rids = [], []
+        for name, seed in cfgs:
+            m = TransformerModel.random_init(get_preset(name), "cuda", seed=seed, std=0.08)
+            e = Engine(m, num_kv_blocks=128, block_size=16, use_graphs=True, name=name)
+            assert (e.stream is None) == serialized
+            engines.append(e)
+            rids.append([e.submit(p, params=params(8, seed=9, temperature=0.7, top_p=0.9), decision_ids=[65, 66])
+                         for p in prompts])
+        run_engines(engines)
+        torch.cuda.synchronize()
+        return [[(e.pop_result(r).token_ids, e.pop_result(r)) for r in rr] for e, rr in zip(engines, rids)]
+
+    def flat(engines_out):
+        return [[t for t, _ in per] for per in engines_out]
+
+    a, b = run(False), run(True)
+    assert flat(a) == flat(b)

@@ -211,3 +211,14 @@ def test_placement_infeasible_reports_error():
     cfg = load_config(str(CONFIGS / "judge_70b_tp4.toml"))
     plan = plan_for_config(cfg, 2)
     assert not plan.feasible and plan.error
+
+
+def test_ensemble_metrics_sections(tiny_ensemble):
+    before = tiny_ensemble.stats()["consensus"].get("answers", 0)
+    tiny_ensemble.ask_many(["One? A) a B) b C) c D) d", "Two? A) a B) b C) c D) d"])
+    st = tiny_ensemble.stats()
+    c = st["consensus"]
+    assert c["answers"] == before + 2 and c["answers_per_s"] > 0
+    assert c["latency_ms.count"] >= 2 and c["rounds.mean"] == 1.0 and 0 < c["agreement.mean"] <= 1
+    assert any(k.startswith("decode_tokens_per_s.") for k in c)
+    assert "kv.prefix_hit_rate" in st["m0"]
