@@ -107,6 +107,14 @@ class _DecodeGraph:
         self.prefix_splits = max(1, min(8, eng.nominal_ctx // 128))
         self.graph: Optional[torch.cuda.CUDAGraph] = None
         self.out_tokens = self.out_lps = self.out_dec = None
+        # pinned landing buffers of the step's results, and the row -> request map the host
+        # mirror was last filled for
+        pin = dev.type == "cuda"
+        self.res_tok = torch.zeros(B, dtype=torch.int32, pin_memory=pin)
+        self.res_lp = torch.zeros(B, dtype=torch.float32, pin_memory=pin)
+        self.res_dec = torch.zeros(B, C, dtype=torch.float32, pin_memory=pin)
+        self.rows_key: Optional[np.ndarray] = None
+        self.any_decision = False
 
     def upload(self) -> None:
         self.arena.copy_(self.host, non_blocking=True)
@@ -188,6 +196,7 @@ class Engine:
         self._graphs: Dict[tuple, _DecodeGraph] = {}
         self._reqs: Dict[int, _ReqState] = {}
         self._done: Dict[int, RequestOutput] = {}
+        self._last_dec = None   # (request ids, chain seeds, decision log-probs) of the newest decode step
         self.metrics = core.Metrics()
 
     # ------------------------------------------------------------------ submission
@@ -362,24 +371,29 @@ class Engine:
         bt = plan.block_tables
         h["block_tables"][:B, : bt.shape[1]] = np.maximum(bt, 0)
         req_ids = plan.request_ids
-        cache: Dict[int, tuple] = {}
-        any_decision = False
-        for b in range(B):
-            rid = int(req_ids[b])
-            e = cache.get(rid)
-            if e is None:
-                p = self.sched.params_of(rid)
-                d = self._reqs[rid].decision_ids
-                e = (p.temperature, p.top_p, p.top_k, d)
-                cache[rid] = e
-            h["temperature"][b], h["top_p"][b], h["top_k"][b] = e[0], e[1], e[2]
-            if e[3]:
-                any_decision = True
-                h["decision_ids"][b, : len(e[3])] = e[3]
-        if B < bucket:
-            h["temperature"][B:] = 0.0
-            h["top_p"][B:] = 1.0
-            h["top_k"][B:] = 0
+        # Per-request sampling parameters only change when the batch composition does; a decode
+        # batch usually keeps its rows for many steps, so the host mirror is refilled only then.
+        if g.rows_key is None or g.rows_key.shape[0] != B or not np.array_equal(g.rows_key, req_ids):
+            cache: Dict[int, tuple] = {}
+            g.any_decision = False
+            for b in range(B):
+                rid = int(req_ids[b])
+                e = cache.get(rid)
+                if e is None:
+                    p = self.sched.params_of(rid)
+                    d = self._reqs[rid].decision_ids
+                    e = (p.temperature, p.top_p, p.top_k, d)
+                    cache[rid] = e
+                h["temperature"][b], h["top_p"][b], h["top_k"][b] = e[0], e[1], e[2]
+                if e[3]:
+                    g.any_decision = True
+                    h["decision_ids"][b, : len(e[3])] = e[3]
+            if B < bucket:
+                h["temperature"][B:] = 0.0
+                h["top_p"][B:] = 1.0
+                h["top_k"][B:] = 0
+            g.rows_key = np.array(req_ids, copy=True)
+        any_decision = g.any_decision
         put("seeds", plan.seeds.astype(np.int64))
         put("steps", plan.step_index)
         if with_prefix:
@@ -405,24 +419,59 @@ class Engine:
             tok, lp, dl = g.out_tokens, g.out_lps, g.out_dec
         else:
             tok, lp, dl = g.run_body(self)
-        return tok, lp, dl, any_decision
+        # Results come back through pinned buffers: the copies are queued right behind the step,
+        # and the host later waits once instead of doing three blocking reads.
+        if self.device.type == "cuda":
+            g.res_tok.copy_(tok, non_blocking=True)
+            g.res_lp.copy_(lp, non_blocking=True)
+            if any_decision:
+                g.res_dec.copy_(dl, non_blocking=True)
+            done = torch.cuda.Event()
+            done.record()
+            return g, done, any_decision
+        g.res_tok, g.res_lp, g.res_dec = tok, lp, dl
+        return g, None, any_decision
 
     def _decode_finish(self, plan, state) -> None:
-        tok, lp, dl, any_decision = state
+        g, done, any_decision = state
+        if done is not None:
+            done.synchronize()
         B = len(plan.seq_ids)
-        req_ids = plan.request_ids
-        tok_h = tok[:B].cpu().numpy()
-        lp_h = lp[:B].cpu().numpy()
+        tok_h = g.res_tok[:B].numpy().astype(np.int32)
+        lp_h = g.res_lp[:B].numpy().astype(np.float32)
         if any_decision:
-            dl_h = dl[:B].cpu().numpy()
-            for b in range(B):
-                st = self._reqs[int(req_ids[b])]
-                if st.decision_ids:
-                    st.decisions[int(plan.seeds[b])] = dl_h[b, : len(st.decision_ids)].tolist()
-        self.sched.complete_decode(plan, tok_h.astype(np.int32), lp_h.astype(np.float32))
+            # A chain's decision log-probs are those of its LAST step. Keeping the newest row
+            # block and resolving rows only when they leave the batch avoids a Python loop
+            # over every row at every step.
+            cur = (np.array(plan.request_ids, copy=True), np.array(plan.seeds, copy=True),
+                   g.res_dec[:B].numpy().copy())
+            self._flush_decisions(keep=cur)
+            self._last_dec = cur
+        self.sched.complete_decode(plan, tok_h, lp_h)
+
+    def _flush_decisions(self, keep=None, only_request: Optional[int] = None) -> None:
+        """Moves rows of the remembered decode step into their requests' ``decisions``: rows that
+        are absent from ``keep`` (the chain finished), or all rows of ``only_request``."""
+        prev = self._last_dec
+        if prev is None:
+            return
+        rids, seeds, vals = prev
+        if only_request is not None:
+            rows = np.nonzero(rids == only_request)[0]
+        else:
+            key_prev = (rids.astype(np.int64) << 32) ^ (seeds.astype(np.int64) & 0xFFFFFFFF)
+            key_cur = (keep[0].astype(np.int64) << 32) ^ (keep[1].astype(np.int64) & 0xFFFFFFFF)
+            if key_prev.shape == key_cur.shape and np.array_equal(key_prev, key_cur):
+                return
+            rows = np.nonzero(~np.isin(key_prev, key_cur))[0]
+        for b in rows:
+            st = self._reqs.get(int(rids[b]))
+            if st is not None and st.decision_ids:
+                st.decisions[int(seeds[b])] = vals[b, : len(st.decision_ids)].tolist()
 
     def _collect(self) -> None:
         for f in self.sched.take_finished():
+            self._flush_decisions(only_request=f.request_id)
             st = self._reqs.pop(f.request_id)
             out = RequestOutput(f.request_id, f.kind, prompt_len=f.prompt_len, cached_tokens=f.cached_tokens,
                                 submitted_at=st.submitted_at, finished_at=time.perf_counter())
