@@ -63,11 +63,8 @@ def main():
                 elif v == "tile":
                     ops.WS_MAX_M, ops.GEMM256_MIN_TILES = 0, -1
                     fns = [lambda lw=lw: ops.linear(X, lw) for lw in lws]
-                elif v == "ws":        # weight-streaming kernel only
-                    ops.M_PANEL_MIN_TILES = 1 << 30
-                    fns = [lambda lw=lw: ops.linear(X, lw, defer_reduce=True) for lw in lws]
-                elif v == "panel":     # single-panel kernel wherever it is legal
-                    ops.M_PANEL_MIN_TILES, ops.M_PANEL_MIN_M = 1, 0
+                elif v in ("ws", "panel"):   # force one of the two decode kernels
+                    ops.DECODE_KERNEL = v
                     fns = [lambda lw=lw: ops.linear(X, lw, defer_reduce=True) for lw in lws]
                 elif v == "g256":
                     if M < 256 or lws[0].n_pad % 256:
@@ -83,7 +80,7 @@ def main():
                 except Exception as ex:  # noqa: BLE001
                     row[v + "_err"] = str(ex)[:80]
                 ops.WS_MAX_M, ops.GEMM256_MIN_TILES = 256, 192
-                ops.M_PANEL_MIN_TILES, ops.M_PANEL_MIN_M = 160, 128
+                ops.DECODE_KERNEL = "panel"
             out.append(row)
             print(row, flush=True)
         del Ws, lws

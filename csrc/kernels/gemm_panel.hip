@@ -1,0 +1,228 @@
+// Skinny GEMM for decode steps: ONE activation panel of BM <= 256 rows against a weight
+// matrix that is streamed from HBM exactly once. Y[M, N] = X[M, K] * W[N, K]^T.
+//
+// At these shapes the weights dominate the traffic (a 7-8B model streams ~15 GB per decode
+// step) and the job is to keep enough loads in flight per CU to saturate HBM while the
+// MFMA work rides along. The kernel is a 128(n) x BM(m) x 64(k) tile whose K loop runs over
+// a deep ring of LDS stages filled by LDS-DMA (global_load_lds, 16 B per lane):
+//
+//     BM    stage (W 16 KiB + X BM*128 B)   stages   K-tiles in flight   wave grid (n x m)   frags / wave
+//     256   48 KiB                          3        2                   2 x 4               4 nt x 4 mt
+//     128   32 KiB                          4        3                   4 x 2               2 nt x 4 mt
+//      64   24 KiB                          6        5                   4 x 2               2 nt x 2 mt
+//      32   20 KiB                          7        6                   4 x 2               2 nt x 1 mt
+//
+// so at BM = 64 a CU has up to 5 x 24 KiB = 120 KiB of loads outstanding, without spending a
+// single VGPR on staging. One barrier per K-tile does both jobs of the ring:
+//
+//     wait vmcnt(P*(D-1))   this wave's P pieces of K-tile t have landed; D-1 tiles stay in flight
+//     barrier               => K-tile t is visible to everybody, and everybody is done with t-1
+//     issue K-tile t+D      into the stage K-tile t-1 occupied
+//     MFMAs of K-tile t
+//
+// Operand conventions as in gemm.hip / gemm256.hip: packed weights (MFMA-fragment order,
+// 1-KiB pieces) are the MFMA A operand; activations are the B operand, staged as 8-row x
+// 128-byte pieces (whole cache lines) into an XOR-swizzled image. blockIdx.y selects a K
+// split (EPI_F32 slabs, summed by the consumer or by lc_splitk_reduce) so that narrow
+// outputs still fill the chip.
+#include "gemm_common.h"
+
+namespace {
+
+constexpr int GP_BN = 128, GP_BK = 64, GP_WBYTES = 16 * 1024;
+
+// DEEP = true: the ring takes (almost) all of a CU's LDS, one workgroup per CU, most loads in
+// flight -- best when the GEMM has the GPU to itself. DEEP = false: a ring of three stages
+// (<= 72 KiB at BM <= 64) so two workgroups fit on a CU -- for ensembles whose member engines
+// run on concurrent streams and fill each other's gaps.
+template <int BM, bool DEEP>
+struct PanelShape {
+  static constexpr int STAGE = GP_WBYTES + BM * 128;
+  static constexpr int NSTAGE = !DEEP ? 3 : (BM >= 256 ? 3 : (BM >= 128 ? 4 : (BM >= 64 ? 6 : 7)));
+  static constexpr int DEPTH = NSTAGE - 1;                 // K-tiles in flight
+  static constexpr int WN = BM >= 256 ? 2 : 4, WM = 8 / WN;  // wave grid
+  static constexpr int NT_W = 8 / WN;                      // n-tiles per wave
+  static constexpr int MT_W = (BM / 16) / WM;              // m-tiles per wave
+  static constexpr int XP = BM / 8 >= 8 ? BM / 64 : 1;     // X pieces a wave issues per K-tile
+  static constexpr int P = 2 + XP;                         // DMA instructions per wave per K-tile
+};
+
+struct GpCtx {
+  const bf16_t* __restrict__ Wp;
+  const bf16_t* __restrict__ X;
+  char* smem;
+  int nt0, M, K, KT, kt_lo, nk, wave, lane;
+};
+
+template <int BM, bool DEEP>
+LC_DEVICE void gp_issue_tile(const GpCtx& c, int t) {
+  using S = PanelShape<BM, DEEP>;
+  if (t >= c.nk) return;
+  char* stage = c.smem + (t % S::NSTAGE) * S::STAGE;
+  const int k_tile = c.kt_lo + t;
+  {
+    const bf16_t* src = c.Wp + (static_cast<size_t>(c.nt0 + c.wave) * c.KT + k_tile * 2) * 512 + c.lane * 8;
+    char* dst = stage + (c.wave * 2) * 1024;
+    __builtin_amdgcn_global_load_lds(LC_GLOBAL_PTR(src), LC_LDS_PTR(dst), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds(LC_GLOBAL_PTR(src + 512), LC_LDS_PTR(dst + 1024), 16, 0, 0);
+  }
+  // Activations: pieces of 8 rows x 128 B. The LDS image of a DMA is lane-linear, so the XOR
+  // swizzle that keeps the fragment reads off each other's banks is applied on the source
+  // side: lane (rr = l>>3, lc = l&7) fetches 16-byte chunk lc^rr of row rr; chunk c of row rr
+  // is later read at position c^rr. With fewer than 8 pieces (BM = 32) waves 4-7 repeat the
+  // pieces of waves 0-3, so that every wave issues the same number of loads.
+  const int rr = c.lane >> 3, lc = c.lane & 7;
+#pragma unroll
+  for (int q = 0; q < S::XP; ++q) {
+    const int piece = (q * 8 + c.wave) % (BM / 8);
+    int row = piece * 8 + rr;
+    row = row < c.M ? row : c.M - 1;
+    const bf16_t* src = c.X + static_cast<size_t>(row) * c.K + k_tile * GP_BK + ((lc ^ rr) << 3);
+    __builtin_amdgcn_global_load_lds(LC_GLOBAL_PTR(src), LC_LDS_PTR(stage + GP_WBYTES + piece * 1024), 16, 0, 0);
+  }
+}
+
+// Byte offset inside the X image of the B fragment (m-tile mt, k-tile kt) for this lane.
+LC_DEVICE int gp_x_off(int mt, int kt, int lane) {
+  const int r = lane & 15, rr = r & 7;
+  return (mt * 2 + (r >> 3)) * 1024 + rr * 128 + (((kt * 4 + (lane >> 4)) ^ rr) << 4);
+}
+
+// s_waitcnt vmcnt(n) needs an immediate: one case per number of K-tiles still in flight.
+template <int P>
+LC_DEVICE void gp_wait_tiles_in_flight(int tiles) {
+  switch (tiles) {
+    case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    case 1: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(P * 1) : "memory"); break;
+    case 2: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(P * 2) : "memory"); break;
+    case 3: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(P * 3) : "memory"); break;
+    case 4: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(P * 4) : "memory"); break;
+    case 5: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(P * 5) : "memory"); break;
+    default: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(P * 6) : "memory"); break;
+  }
+}
+
+template <int BM, bool DEEP, int EPI>
+__global__ __launch_bounds__(512) void gemm_panel_kernel(const bf16_t* __restrict__ Wp,
+                                                         const bf16_t* __restrict__ X, void* __restrict__ Y,
+                                                         const bf16_t* __restrict__ bias, int M, int N, int K,
+                                                         int ldy, int nk_per_split) {
+  using S = PanelShape<BM, DEEP>;
+  static_assert(S::P * S::DEPTH <= 63, "vmcnt is a 6-bit counter");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wn = wave % S::WN, wm = wave / S::WN;
+  GpCtx c{Wp, X, smem, static_cast<int>(blockIdx.x) * (GP_BN / 16), M, K, K / 32,
+          static_cast<int>(blockIdx.y) * nk_per_split, nk_per_split, wave, lane};
+
+  f32x4 acc[S::NT_W][S::MT_W];
+#pragma unroll
+  for (int i = 0; i < S::NT_W; ++i)
+#pragma unroll
+    for (int j = 0; j < S::MT_W; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+#pragma unroll
+  for (int t = 0; t < S::DEPTH; ++t) gp_issue_tile<BM, DEEP>(c, t);
+
+  for (int t = 0; t < c.nk; ++t) {
+    const int behind = c.nk - 1 - t;   // K-tiles after t that exist at all
+    gp_wait_tiles_in_flight<S::P>(behind < S::DEPTH - 1 ? behind : S::DEPTH - 1);
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    gp_issue_tile<BM, DEEP>(c, t + S::DEPTH);
+
+    const char* stage = smem + (t % S::NSTAGE) * S::STAGE;
+    const char* wimg = stage + (wn * S::NT_W * 2) * 1024 + lane * 16;
+    const char* ximg = stage + GP_WBYTES;
+    bf16x8 a[S::NT_W][2], b[S::MT_W][2];
+#pragma unroll
+    for (int i = 0; i < S::NT_W; ++i)
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt) a[i][kt] = *reinterpret_cast<const bf16x8*>(wimg + (i * 2 + kt) * 1024);
+#pragma unroll
+    for (int j = 0; j < S::MT_W; ++j)
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt)
+        b[j][kt] = *reinterpret_cast<const bf16x8*>(ximg + gp_x_off(wm * S::MT_W + j, kt, lane));
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int j = 0; j < S::MT_W; ++j)
+#pragma unroll
+        for (int i = 0; i < S::NT_W; ++i)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][kt], b[j][kt], acc[i][j], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+    // every LDS read of this K-tile has been consumed by an MFMA above, so passing the next
+    // barrier implies this wave is done with the stage
+  }
+
+  const int nbase = blockIdx.x * GP_BN + wn * (S::NT_W * 16), mbase = wm * (S::MT_W * 16);
+  const size_t slab = (EPI == EPI_F32) ? static_cast<size_t>(blockIdx.y) * M * ldy : 0;
+  const bf16_t* eb = gridDim.y > 1 ? nullptr : bias;   // split-K: the reducer adds the bias
+#pragma unroll
+  for (int i = 0; i < S::NT_W; ++i)
+#pragma unroll
+    for (int j = 0; j < S::MT_W; ++j) {
+      if constexpr (EPI == EPI_SWIGLU) {
+        if (i & 1) continue;
+        store_tile<EPI>(acc[i][j], &acc[(i + 1) % S::NT_W][j], Y, eb, mbase + j * 16, nbase + i * 16, M, N, ldy,
+                        lane, 0);
+      } else {
+        store_tile<EPI>(acc[i][j], nullptr, Y, eb, mbase + j * 16, nbase + i * 16, M, N, ldy, lane, slab);
+      }
+    }
+}
+
+template <int BM, bool DEEP>
+int launch_panel(int epi, const bf16_t* w, const bf16_t* x, void* Y, const bf16_t* b, int M, int N, int K,
+                 int n_pad, int ldy, int splits, hipStream_t stream) {
+  using S = PanelShape<BM, DEEP>;
+  const dim3 grid(n_pad / GP_BN, splits), block(512);
+  const int lds = S::NSTAGE * S::STAGE;
+  const int nk = (K / GP_BK) / splits;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_panel_kernel<BM, DEEP, EPI_BF16>),
+                        hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_panel_kernel<BM, DEEP, EPI_F32>),
+                        hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_panel_kernel<BM, DEEP, EPI_SWIGLU>),
+                        hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    attr_set = true;
+  }
+  if (epi == EPI_BF16)
+    gemm_panel_kernel<BM, DEEP, EPI_BF16><<<grid, block, lds, stream>>>(w, x, Y, b, M, N, K, ldy, nk);
+  else if (epi == EPI_F32)
+    gemm_panel_kernel<BM, DEEP, EPI_F32><<<grid, block, lds, stream>>>(w, x, Y, b, M, N, K, ldy, nk);
+  else if (epi == EPI_SWIGLU)
+    gemm_panel_kernel<BM, DEEP, EPI_SWIGLU><<<grid, block, lds, stream>>>(w, x, Y, b, M, N, K, ldy, nk);
+  else
+    return -2;
+  return static_cast<int>(hipGetLastError());
+}
+
+}  // namespace
+
+// Y[M<=256, N] = X * W^T. Requirements: K % 64 == 0, (K/64) % splits == 0, n_pad % 128 == 0.
+// splits > 1 requires epi == EPI_F32 and Y = fp32 workspace [splits, M, ldy]. deep = 0 selects the
+// three-stage ring (two workgroups per CU) for M <= 128.
+LC_EXPORT int lc_gemm_panel(const void* Wp, const void* X, void* Y, const void* bias, int M, int N, int K,
+                            int n_pad, int ldy, int epi, int splits, int deep, hipStream_t stream) {
+  if (M <= 0) return 0;
+  if (M > 256 || K % 64 || n_pad % GP_BN || N > n_pad || splits < 1 || (K / GP_BK) % splits) return -1;
+  if (splits > 1 && epi != EPI_F32) return -1;
+  auto w = static_cast<const bf16_t*>(Wp);
+  auto x = static_cast<const bf16_t*>(X);
+  auto b = static_cast<const bf16_t*>(bias);
+#define LC_PANEL(BM_)                                                                            \
+  return deep ? launch_panel<BM_, true>(epi, w, x, Y, b, M, N, K, n_pad, ldy, splits, stream)    \
+              : launch_panel<BM_, false>(epi, w, x, Y, b, M, N, K, n_pad, ldy, splits, stream)
+  if (M <= 32) LC_PANEL(32);
+  if (M <= 64) LC_PANEL(64);
+  if (M <= 128) LC_PANEL(128);
+  return launch_panel<256, true>(epi, w, x, Y, b, M, N, K, n_pad, ldy, splits, stream);
+#undef LC_PANEL
+}

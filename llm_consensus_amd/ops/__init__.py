@@ -22,10 +22,22 @@ WS_MAX_M = int(os.environ.get("LC_WS_MAX_M", "256"))
 # The 256x256 pipelined kernel runs one workgroup per CU: use it once a launch has at least this
 # many 256x256 tiles (fewer tiles leave CUs idle; the 128x128 kernel fills the chip better). -1 disables.
 GEMM256_MIN_TILES = int(os.environ.get("LC_GEMM256_MIN_TILES", "192"))
-# Single-panel kernel (gemm_m256.hip): used for M_PANEL_MIN_M < M <= 256 once there are this many
-# 128-column tiles (a large value disables it).
-M_PANEL_MIN_M = int(os.environ.get("LC_M_PANEL_MIN_M", "128"))
-M_PANEL_MIN_TILES = int(os.environ.get("LC_M_PANEL_MIN_TILES", "160"))
+# Decode GEMM for 17..256 rows: "panel" (gemm_panel.hip, deep LDS-DMA ring) or "ws" (weight-streaming
+# wsgemm in gemm.hip, kept for comparison), and the panel kernel's split-K policy.
+DECODE_KERNEL = os.environ.get("LC_DECODE_KERNEL", "panel")
+PANEL_MAX_BLOCKS = int(os.environ.get("LC_PANEL_MAX_BLOCKS", "256"))
+PANEL_MIN_KTILES = int(os.environ.get("LC_PANEL_MIN_KTILES", "4"))
+# Ring depth of the panel kernel for M <= 128: deep (all of a CU's LDS, one workgroup per CU, fastest
+# alone) or three stages (two workgroups per CU, for member engines that share the GPU on
+# concurrent streams). Chosen when a decode graph is captured; see set_concurrent_engines().
+PANEL_DEEP = os.environ.get("LC_PANEL_DEEP", "1") == "1"
+
+
+def set_concurrent_engines(n: int) -> None:
+    """Tells the op layer how many engines will issue decode steps on concurrent streams."""
+    global PANEL_DEEP
+    if "LC_PANEL_DEEP" not in os.environ:
+        PANEL_DEEP = n <= 1
 # In-workgroup K-split decode kernel (kgemm.hip): widest output it is used for, and a test override
 # (-1 = automatic, 0 = never, 1/2/4 = force that many n-tiles per workgroup).
 KGEMM_MAX_N = int(os.environ.get("LC_KGEMM_MAX_N", "8192"))
@@ -134,6 +146,22 @@ def _choose_splits(n_pad: int, K: int, M: int, allow: bool) -> int:
     return best
 
 
+def _choose_panel_splits(n_pad: int, K: int) -> int:
+    """K splits of the panel kernel (gemm_panel.hip). Its LDS ring admits one workgroup per CU,
+    so the aim is as many workgroups as possible WITHOUT exceeding the 256 CUs (a 257th would
+    run alone in a second round); every split is a whole number of 64-deep K-tiles and at
+    least PANEL_MIN_KTILES of them."""
+    blocks = n_pad // 128
+    nk = K // 64
+    best = 1
+    for s in (2, 3, 4, 5, 6, 7, 8, 12, 14, 16):
+        if blocks * s > PANEL_MAX_BLOCKS:
+            break
+        if nk % s == 0 and nk // s >= PANEL_MIN_KTILES:
+            best = s
+    return best
+
+
 @dataclass
 class PartialSum:
     """Un-reduced output of a split-K GEMM: ``part`` holds S fp32 slabs [S, M, N] whose sum
@@ -176,14 +204,6 @@ def linear(x: torch.Tensor, w: LinearWeight, out_f32: bool = False, defer_reduce
     y = torch.empty(M, out_n, dtype=torch.float32 if (out_f32 and not w.swiglu) else torch.bfloat16, device=x.device)
     if M == 0:
         return y
-    # 129..256 rows against a wide matrix (gate/up and vocabulary projections of a K-chain decode
-    # step): the 128x256 single-panel kernel gives every CU one MFMA-dense tile; streaming the
-    # weights past 16 m-tiles held in LDS is LDS-bound there (measured at N=28672, K=4096, M=256).
-    # Past 256 such tiles a second round would start; 256x256 tiles (half as many) are better then.
-    if M_PANEL_MIN_M < M <= 256 and w.n_pad // 128 >= M_PANEL_MIN_TILES and w.k >= 128:
-        kernel = "lc_gemm256" if (w.n_pad // 128 > 256 and w.n_pad % 256 == 0) else "lc_gemm_m256"
-        h.call(kernel, w.data.data_ptr(), x.data_ptr(), y.data_ptr(), h.ptr(w.bias), M, w.n, w.k, w.n_pad, out_n, epi)
-        return y
     if M > WS_MAX_M:
         tiles256 = ((M + 255) // 256) * (w.n_pad // 256)
         if GEMM256_MIN_TILES >= 0 and w.n_pad % 256 == 0 and tiles256 >= GEMM256_MIN_TILES:
@@ -193,19 +213,29 @@ def linear(x: torch.Tensor, w: LinearWeight, out_f32: bool = False, defer_reduce
         h.call("lc_gemm_tile", w.data.data_ptr(), x.data_ptr(), y.data_ptr(), h.ptr(w.bias), M, w.n, w.k, w.n_pad,
                out_n, epi)
         return y
+    # ---- decode shapes: one activation panel of at most 256 rows ----
     ntw = _kgemm_ntw(w.n_pad, M, w.swiglu)
-    if ntw:
+    if ntw:   # a handful of rows, narrow output: K split over the waves of one workgroup
         h.call("lc_kgemm", w.data.data_ptr(), x.data_ptr(), y.data_ptr(), h.ptr(w.bias), M, w.n, w.k, w.n_pad,
                out_n, epi, ntw)
         return y
-    splits = _choose_splits(w.n_pad, w.k, M, allow=True)
+    # 129..256 rows against more than 256 column tiles (vocabulary projection, very wide gate/up):
+    # a second round of 128-column tiles would start; 256x256 tiles (half as many) do better.
+    if M > 128 and w.n_pad // 128 > 256 and w.n_pad % 256 == 0 and GEMM256_MIN_TILES >= 0:
+        h.call("lc_gemm256", w.data.data_ptr(), x.data_ptr(), y.data_ptr(), h.ptr(w.bias), M, w.n, w.k, w.n_pad,
+               out_n, epi)
+        return y
+    if DECODE_KERNEL == "panel":
+        kernel, splits, extra = "lc_gemm_panel", _choose_panel_splits(w.n_pad, w.k), (1 if PANEL_DEEP else 0,)
+    else:
+        kernel, splits, extra = "lc_wsgemm", _choose_splits(w.n_pad, w.k, M, allow=True), ()
     if splits == 1:
-        h.call("lc_wsgemm", w.data.data_ptr(), x.data_ptr(), y.data_ptr(), h.ptr(w.bias), M, w.n, w.k, w.n_pad,
-               out_n, epi, 1)
+        h.call(kernel, w.data.data_ptr(), x.data_ptr(), y.data_ptr(), h.ptr(w.bias), M, w.n, w.k, w.n_pad, out_n, epi, 1,
+               *extra)
         return y
     part = torch.empty(splits, M, w.n, dtype=torch.float32, device=x.device)
-    h.call("lc_wsgemm", w.data.data_ptr(), x.data_ptr(), part.data_ptr(), None, M, w.n, w.k, w.n_pad, w.n, EPI_F32,
-           splits)
+    h.call(kernel, w.data.data_ptr(), x.data_ptr(), part.data_ptr(), None, M, w.n, w.k, w.n_pad, w.n, EPI_F32, splits,
+           *extra)
     if defer_reduce and not w.swiglu and not out_f32:
         return PartialSum(part, w.bias)
     mode = 2 if w.swiglu else (1 if out_f32 else 0)

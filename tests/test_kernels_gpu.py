@@ -557,10 +557,13 @@ def test_rope_kv_write_sums_splitk_partials(Dh, with_bias):
     assert torch.equal(q1[:, : Hq * Dh], q2[:, : Hq * Dh])
 
 
-@pytest.mark.parametrize("M,N,K,swiglu,bias", [(256, 512, 256, False, False), (200, 384, 1024, True, False),
-                                               (129, 1280, 128, False, True), (256, 2048, 4096, True, True),
-                                               (1, 256, 192, False, False)])
-def test_gemm_m256_panel_kernel(M, N, K, swiglu, bias):
+@pytest.mark.parametrize("M,N,K,swiglu,bias,splits", [
+    (256, 512, 256, False, False, 1), (200, 384, 1024, True, False, 1), (129, 1280, 128, False, True, 1),
+    (256, 2048, 4096, True, True, 1), (1, 256, 192, False, False, 1), (64, 640, 1024, False, True, 1),
+    (64, 384, 2048, False, False, 4), (33, 256, 3584, False, True, 7), (17, 512, 512, True, False, 1),
+    (128, 256, 4096, False, False, 8), (100, 4096, 896, True, False, 1), (32, 128, 64, False, False, 1)])
+@pytest.mark.parametrize("deep", [1, 0])
+def test_gemm_panel_kernel(M, N, K, swiglu, bias, splits, deep):
     from llm_consensus_amd.ops import hip as h
 
     W = bf(rand(N, K, scale=0.1, seed=1))
@@ -568,15 +571,22 @@ def test_gemm_m256_panel_kernel(M, N, K, swiglu, bias):
     x = bf(rand(M, K, scale=0.5, seed=3))
     lw = ops.LinearWeight.from_dense(W, b, DEV, swiglu=swiglu)
     out_n = N // 2 if swiglu else N
-    y = torch.empty(M, out_n, dtype=torch.bfloat16, device=DEV)
     xd = x.to(DEV)
-    h.call("lc_gemm_m256", lw.data.data_ptr(), xd.data_ptr(), y.data_ptr(), h.ptr(lw.bias), M, N, K, lw.n_pad, out_n,
-           ops.EPI_SWIGLU if swiglu else ops.EPI_BF16)
+
+    def run():
+        if splits == 1:
+            y = torch.empty(M, out_n, dtype=torch.bfloat16, device=DEV)
+            h.call("lc_gemm_panel", lw.data.data_ptr(), xd.data_ptr(), y.data_ptr(), h.ptr(lw.bias), M, N, K, lw.n_pad,
+                   out_n, ops.EPI_SWIGLU if swiglu else ops.EPI_BF16, 1, deep)
+            return y
+        part = torch.empty(splits, M, N, dtype=torch.float32, device=DEV)
+        h.call("lc_gemm_panel", lw.data.data_ptr(), xd.data_ptr(), part.data_ptr(), None, M, N, K, lw.n_pad, N,
+               ops.EPI_F32, splits, deep)
+        return ops.PartialSum(part, lw.bias).reduce()
+
+    y = run()
     want = ops.linear(x, ops.LinearWeight.from_dense(W, b, "cpu", swiglu=swiglu), out_f32=True)
     assert rel_err(y.float().cpu(), want) < 1e-2
     # repeated launches give identical bits (no race between the DMA ring and the readers)
     for _ in range(20):
-        y2 = torch.empty_like(y)
-        h.call("lc_gemm_m256", lw.data.data_ptr(), xd.data_ptr(), y2.data_ptr(), h.ptr(lw.bias), M, N, K, lw.n_pad,
-               out_n, ops.EPI_SWIGLU if swiglu else ops.EPI_BF16)
-        assert torch.equal(y, y2)
+        assert torch.equal(y, run())
