@@ -33,6 +33,10 @@ PANEL_MIN_KTILES = int(os.environ.get("LC_PANEL_MIN_KTILES", "4"))
 PANEL_DEEP = os.environ.get("LC_PANEL_DEEP", "1") == "1"
 
 
+# Decode attention: how many of the KV splits the waves of one workgroup may take (1, 2 or 4).
+ATTN_DECODE_MAX_WAVES = int(os.environ.get("LC_ATTN_WAVES", "4"))
+
+
 def set_concurrent_engines(n: int) -> None:
     """Tells the op layer how many engines will issue decode steps on concurrent streams."""
     global PANEL_DEEP
@@ -378,6 +382,7 @@ def attn_decode(qkv, k_cache, vt_cache, block_tables, ctx_lens, Hq, Hkv, Dh, sca
     # Up to four of the requested KV splits are taken by the waves of one workgroup, which
     # merges them on chip; only the remaining factor produces partial slots in HBM.
     waves = (4 if nsplit >= 4 else (2 if nsplit >= 2 else 1)) if Hq // Hkv <= 8 else 1
+    waves = min(waves, ATTN_DECODE_MAX_WAVES)
     nsplit = max(1, nsplit // waves)
     if nsplit == 1 and not use_prefix:
         h.call("lc_attn_decode", qkv.data_ptr(), qkv.stride(0), k_cache.data_ptr(), vt_cache.data_ptr(),
