@@ -3,7 +3,7 @@ layers' worth of distinct caches (>= 1.5 GB) are walked inside one hipGraph so e
 misses the last-level cache, as a real model's 32 layers do. Reports us per call and the
 KV-stream bandwidth for 1-, 2- and 4-wave workgroups.
 
-  python benchmarks/attn_decode_bench.py [B] [ctx]      (default 64 544)
+  python benchmarks/attn_decode_bench.py [B] [ctx] [nsplit]      (default 64 544 auto)
 """
 import os
 import sys
@@ -29,7 +29,7 @@ def main():
     bt = torch.arange(nblk, dtype=torch.int32, device=DEV).view(B, nb_seq)
     ctx = torch.full((B,), ctx_len, dtype=torch.int32, device=DEV)
     qkv = (torch.randn(B, (Hq + 2 * Hkv) * Dh, device=DEV) * 0.5).bfloat16()
-    nsplit = ops.choose_kv_splits(B, Hkv, 1024)
+    nsplit = int(sys.argv[3]) if len(sys.argv) > 3 else ops.choose_kv_splits(B, Hkv, 1024)
     print(f"B={B} ctx={ctx_len} layers={layers} nsplit={nsplit} kv={kv_bytes / 1e6:.0f} MB/call")
     ref = None
     for waves in (1, 2, 4):

@@ -357,9 +357,13 @@ def attn_prefill(qkv, k_cache, vt_cache, block_tables, cu_q, ctx_lens, max_q_len
 
 
 def choose_kv_splits(B: int, Hkv: int, max_ctx: int) -> int:
-    """Enough waves to occupy the chip (256 CUs x several waves) without slicing below 128 keys."""
+    """KV splits per (sequence, kv head): about 1024 waves in total (4 per CU) without slicing
+    below 128 keys. Measured with an HBM-resident cache (benchmarks/attn_decode_bench.py): fewer
+    waves leave the memory pipe short of requests, more waves shorten every wave's key loop
+    until its fixed cost (query load, block-table walk, merge) dominates: 64 sequences x 8 kv
+    heads x 544 keys run at 3.0 / 4.2 / 3.7 / 2.7 TB/s with 1 / 2 / 4 / 8 splits."""
     waves = max(1, B * Hkv)
-    want = max(1, 2048 // waves)
+    want = max(1, 1024 // waves)
     cap = max(1, max_ctx // 128)
     return int(max(1, min(want, cap, 16)))
 
