@@ -40,6 +40,60 @@ struct AttnState {
   float m, l;         // running max (log2 domain) and this lane-half's partial sum
 };
 
+// One 32-key tile for the wave's 32 query rows, operands already in registers: S^T = K * Q^T,
+// online softmax, O^T += Vt * P^T. Row visibility: lo_q <= key < hi_q.
+template <int DH>
+LC_DEVICE void process_tile(AttnState<DH>& st, const bf16x8 (&qf)[DH / 16], const bf16x8 (&kf)[DH / 16],
+                            const bf16x8 (&vf)[DH / 32][2], int k0, int lo_q, int hi_q, float scale2, int lane) {
+  const int h = lane >> 5;
+  f32x16 sc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int kk = 0; kk < DH / 16; ++kk)
+    sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[kk], qf[kk], sc, 0, 0, 0);
+
+  // ---- online softmax (row q = lane&31; this lane holds keys k0 + 16*(reg>>3) + 8h + (reg&7)) ----
+  float tmax = kNegBig;
+  bool vis[16];
+#pragma unroll
+  for (int g = 0; g < 16; ++g) {
+    const int kidx = k0 + 16 * (g >> 3) + 8 * h + (g & 7);
+    vis[g] = (kidx >= lo_q) && (kidx < hi_q);
+    sc[g] = vis[g] ? sc[g] * scale2 : kNegBig;
+    tmax = fmaxf(tmax, sc[g]);
+  }
+  tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+  const float m_new = fmaxf(st.m, tmax);
+  const float alpha = exp2f(st.m - m_new);
+  st.m = m_new;
+  float psum = 0.f;
+#pragma unroll
+  for (int g = 0; g < 16; ++g) {
+    const float p = vis[g] ? exp2f(sc[g] - m_new) : 0.f;
+    sc[g] = p;
+    psum += p;
+  }
+  st.l = st.l * alpha + psum;
+#pragma unroll
+  for (int b = 0; b < DH / 32; ++b)
+#pragma unroll
+    for (int g = 0; g < 16; ++g) st.o[b][g] *= alpha;
+
+  // ---- O^T += Vt * P^T ----
+  bf16x8 pf[2];
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    u32x4 packed;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) packed[j] = pack_bf16x2(sc[8 * s + 2 * j], sc[8 * s + 2 * j + 1]);
+    pf[s] = __builtin_bit_cast(bf16x8, packed);
+  }
+#pragma unroll
+  for (int b = 0; b < DH / 32; ++b)
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+      st.o[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[b][s], pf[s], st.o[b], 0, 0, 0);
+}
+
 // Processes keys [kv_lo, kv_hi) for the wave's 32 rows. Row visibility: lo_q <= key < hi_q.
 template <int DH>
 LC_DEVICE void attend_range(AttnState<DH>& st, const bf16x8 (&qf)[DH / 16], const TileCtx& c, int kv_lo,
@@ -69,52 +123,7 @@ LC_DEVICE void attend_range(AttnState<DH>& st, const bf16x8 (&qf)[DH / 16], cons
       for (int b = 0; b < DH / 32; ++b)
         vf[b][s] = *reinterpret_cast<const bf16x8*>(vp + static_cast<size_t>(b) * 32 * c.BS);
     }
-    f32x16 sc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int kk = 0; kk < DH / 16; ++kk)
-      sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[kk], qf[kk], sc, 0, 0, 0);
-
-    // ---- online softmax (row q = lane&31; this lane holds keys k0 + 16*(reg>>3) + 8h + (reg&7)) ----
-    float tmax = kNegBig;
-    bool vis[16];
-#pragma unroll
-    for (int g = 0; g < 16; ++g) {
-      const int kidx = k0 + 16 * (g >> 3) + 8 * h + (g & 7);
-      vis[g] = (kidx >= lo_q) && (kidx < hi_q);
-      sc[g] = vis[g] ? sc[g] * c.scale2 : kNegBig;
-      tmax = fmaxf(tmax, sc[g]);
-    }
-    tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
-    const float m_new = fmaxf(st.m, tmax);
-    const float alpha = exp2f(st.m - m_new);
-    st.m = m_new;
-    float psum = 0.f;
-#pragma unroll
-    for (int g = 0; g < 16; ++g) {
-      const float p = vis[g] ? exp2f(sc[g] - m_new) : 0.f;
-      sc[g] = p;
-      psum += p;
-    }
-    st.l = st.l * alpha + psum;
-#pragma unroll
-    for (int b = 0; b < DH / 32; ++b)
-#pragma unroll
-      for (int g = 0; g < 16; ++g) st.o[b][g] *= alpha;
-
-    // ---- O^T += Vt * P^T ----
-    bf16x8 pf[2];
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      u32x4 packed;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) packed[j] = pack_bf16x2(sc[8 * s + 2 * j], sc[8 * s + 2 * j + 1]);
-      pf[s] = __builtin_bit_cast(bf16x8, packed);
-    }
-#pragma unroll
-    for (int b = 0; b < DH / 32; ++b)
-#pragma unroll
-      for (int s = 0; s < 2; ++s)
-        st.o[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[b][s], pf[s], st.o[b], 0, 0, 0);
+    process_tile<DH>(st, qf, kf, vf, k0, lo_q, hi_q, c.scale2, lane);
   }
 }
 
@@ -201,6 +210,135 @@ __global__ __launch_bounds__(512) void attn_prefill_kernel(const bf16_t* __restr
     kv_lo = first_pos + 1 > window ? first_pos + 1 - window : 0;
   }
   attend_range<DH>(st, qf, c, kv_lo, kv_hi, lo_q, hi_q, lane);
+  bf16_t* orow = valid ? out + static_cast<size_t>(q0 + i) * (Hq * DH) + head * DH : nullptr;
+  finish_and_store<DH>(st, orow, nullptr, nullptr, lane);
+}
+
+// ------------------------------------------------------------------ prefill, K/V through LDS
+// Same work split (grid (q_tile, kv_head, seq); the G waves of a workgroup are the G query heads
+// that share the kv head, 32 query rows each), but the 32-key K/V tiles are staged ONCE per
+// workgroup in LDS by LDS-DMA and every wave reads its MFMA fragments from there, instead of
+// each wave pulling the same 16 KiB per tile through the vector L1. A ring of PF_NSTAGE
+// stages keeps two tiles in flight; one barrier per tile does both jobs of the ring (tile t
+// visible to all, tile t-1 released), exactly as in gemm_panel.hip.
+//
+// LDS images (per stage): K = 32 keys x Dh*2 bytes, rows whole; V^T = Dh rows x 64 bytes (32
+// keys). A DMA writes lane-linear, so the bank swizzle is applied to the SOURCE chunk a lane
+// fetches: K position (key, c) holds chunk c ^ (key & (CH-1)) of that key, V position (d, c)
+// holds chunk c ^ ((d >> 2) & 3) of row d. Fragment reads apply the same XOR.
+constexpr int PF_NSTAGE = 3;
+
+template <int DH>
+struct PrefillLds {
+  static constexpr int CH = DH / 8;              // 16-byte chunks per key row
+  static constexpr int KEYS_PER_PIECE = 64 / CH;  // a DMA instruction moves 64 chunks
+  static constexpr int K_PIECES = 32 / KEYS_PER_PIECE;
+  static constexpr int V_PIECES = DH / 16;       // 16 d-rows x 4 chunks per piece
+  static constexpr int PIECES = K_PIECES + V_PIECES;
+  static constexpr int K_BYTES = 32 * DH * 2;
+  static constexpr int STAGE = 2 * K_BYTES;
+};
+
+template <int DH>
+__global__ __launch_bounds__(512) void attn_prefill_lds_kernel(
+    const bf16_t* __restrict__ Q, int q_stride, const bf16_t* __restrict__ Kc, const bf16_t* __restrict__ Vt,
+    const int32_t* __restrict__ block_tables, int max_blocks, const int32_t* __restrict__ cu_q,
+    const int32_t* __restrict__ ctx_lens, bf16_t* __restrict__ out, int Hq, int Hkv, int lbs, float scale2,
+    int window, int ppw) {
+  using L = PrefillLds<DH>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int s = blockIdx.z, kvh = blockIdx.y, tile = blockIdx.x;
+  const int q0 = cu_q[s], q_len = cu_q[s + 1] - q0;
+  if (tile * 32 >= q_len) return;
+  const int lane = threadIdx.x & 63;
+  const int g = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int G = Hq / Hkv;
+  const int head = kvh * G + g;
+  const int ctx = ctx_lens[s];
+  const int base_pos = ctx - q_len;
+  const int i = tile * 32 + (lane & 31);
+  const bool valid = i < q_len;
+  const int pos = base_pos + i;
+  const int hi_q = valid ? pos + 1 : 0;
+  const int lo_q = (valid && window > 0 && pos + 1 > window) ? pos + 1 - window : 0;
+  const int BS = 1 << lbs;
+  const int32_t* bt = block_tables + static_cast<size_t>(s) * max_blocks;
+  const size_t kblk_stride = static_cast<size_t>(Hkv) * BS * DH;
+
+  bf16x8 qf[DH / 16];
+  load_q<DH>(qf, valid ? Q + static_cast<size_t>(q0 + i) * q_stride + head * DH : nullptr, lane);
+  AttnState<DH> st;
+  init_state<DH>(st);
+
+  const int last_row = min(tile * 32 + 31, q_len - 1);
+  const int kv_hi = base_pos + last_row + 1;
+  int kv_lo = 0;
+  if (window > 0) {
+    const int first_pos = base_pos + tile * 32;
+    kv_lo = first_pos + 1 > window ? first_pos + 1 - window : 0;
+  }
+  const int t_lo = kv_lo >> 5, nt = ((kv_hi + 31) >> 5) - t_lo;   // 32-key tiles [t_lo, t_lo + nt)
+
+  // Every wave issues `ppw` pieces per tile (pieces beyond L::PIECES wrap around: a duplicate
+  // write of the same bytes), so all waves count the same number of loads.
+  auto issue_tile = [&](int t) {
+    if (t >= nt) return;
+    char* stage = smem + (t % PF_NSTAGE) * L::STAGE;
+    const int k0 = (t_lo + t) << 5;
+    for (int q = 0; q < ppw; ++q) {
+      const int piece = (q * G + g) % L::PIECES;
+      if (piece < L::K_PIECES) {
+        const int kl = piece * L::KEYS_PER_PIECE + lane / L::CH, lc = lane % L::CH;   // key in tile, position
+        int key = k0 + kl;
+        key = key < kv_hi ? key : kv_hi - 1;
+        const bf16_t* src = Kc + static_cast<size_t>(bt[key >> lbs]) * kblk_stride +
+                            (static_cast<size_t>(kvh) * BS + (key & (BS - 1))) * DH + ((lc ^ (kl & (L::CH - 1))) << 3);
+        __builtin_amdgcn_global_load_lds(LC_GLOBAL_PTR(src), LC_LDS_PTR(stage + piece * 1024), 16, 0, 0);
+      } else {
+        const int vp = piece - L::K_PIECES;
+        const int d = vp * 16 + (lane >> 2), lc = lane & 3;
+        int key8 = k0 + 8 * (lc ^ ((d >> 2) & 3));
+        const int last8 = (kv_hi - 1) & ~7;
+        key8 = key8 < kv_hi ? key8 : last8;
+        const bf16_t* src = Vt + static_cast<size_t>(bt[key8 >> lbs]) * kblk_stride +
+                            (static_cast<size_t>(kvh) * DH + d) * BS + (key8 & (BS - 1));
+        __builtin_amdgcn_global_load_lds(LC_GLOBAL_PTR(src), LC_LDS_PTR(stage + L::K_BYTES + vp * 1024), 16, 0, 0);
+      }
+    }
+  };
+  auto wait_in_flight = [&](int tiles) {   // ppw is 1..4 and at most one tile stays in flight
+    if (tiles == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if (ppw == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+    else if (ppw == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    else if (ppw == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  };
+
+  const int r = lane & 31, h = lane >> 5;
+  const int pi_r = (r & ~0xC) | ((r & 4) << 1) | ((r & 8) >> 1);
+  issue_tile(0);
+  issue_tile(1);
+  for (int t = 0; t < nt; ++t) {
+    wait_in_flight(t + 1 < nt ? 1 : 0);
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    issue_tile(t + 2);
+    const char* stage = smem + (t % PF_NSTAGE) * L::STAGE;
+    const int k0 = (t_lo + t) << 5;
+    bf16x8 kf[DH / 16], vf[DH / 32][2];
+#pragma unroll
+    for (int kk = 0; kk < DH / 16; ++kk)
+      kf[kk] = *reinterpret_cast<const bf16x8*>(stage + pi_r * (DH * 2) + (((2 * kk + h) ^ (pi_r & (L::CH - 1))) << 4));
+#pragma unroll
+    for (int sx = 0; sx < 2; ++sx)
+#pragma unroll
+      for (int b = 0; b < DH / 32; ++b) {
+        const int d = b * 32 + r;
+        vf[b][sx] = *reinterpret_cast<const bf16x8*>(stage + L::K_BYTES + d * 64 + (((2 * sx + h) ^ ((d >> 2) & 3)) << 4));
+      }
+    process_tile<DH>(st, qf, kf, vf, k0, lo_q, hi_q, scale2, lane);
+  }
   bf16_t* orow = valid ? out + static_cast<size_t>(q0 + i) * (Hq * DH) + head * DH : nullptr;
   finish_and_store<DH>(st, orow, nullptr, nullptr, lane);
 }
@@ -432,8 +570,21 @@ LC_EXPORT int lc_attn_prefill(const void* Q, int q_stride, const void* Kc, const
   static_cast<const bf16_t*>(Q), q_stride, static_cast<const bf16_t*>(Kc), static_cast<const bf16_t*>(Vt), \
       static_cast<const int32_t*>(block_tables), max_blocks, static_cast<const int32_t*>(cu_q),          \
       static_cast<const int32_t*>(ctx_lens), static_cast<bf16_t*>(out), Hq, Hkv, lbs, scale2, window
-  if (Dh == 128) attn_prefill_kernel<128><<<grid, block, 0, stream>>>(LC_ARGS);
-  else attn_prefill_kernel<64><<<grid, block, 0, stream>>>(LC_ARGS);
+  // K/V through LDS when the G waves of a workgroup can move a tile with at most 4 DMA
+  // instructions each (G >= 4 at Dh = 128, G >= 2 at Dh = 64); otherwise straight to registers.
+  const int G = Hq / Hkv;
+  const int pieces = Dh == 128 ? PrefillLds<128>::PIECES : PrefillLds<64>::PIECES;
+  const int ppw = (pieces + G - 1) / G;
+  if (ppw <= 4) {
+    if (Dh == 128)
+      attn_prefill_lds_kernel<128><<<grid, block, PF_NSTAGE * PrefillLds<128>::STAGE, stream>>>(LC_ARGS, ppw);
+    else
+      attn_prefill_lds_kernel<64><<<grid, block, PF_NSTAGE * PrefillLds<64>::STAGE, stream>>>(LC_ARGS, ppw);
+  } else if (Dh == 128) {
+    attn_prefill_kernel<128><<<grid, block, 0, stream>>>(LC_ARGS);
+  } else {
+    attn_prefill_kernel<64><<<grid, block, 0, stream>>>(LC_ARGS);
+  }
 #undef LC_ARGS
   LC_RETURN_LAST_ERROR();
 }

@@ -319,19 +319,29 @@ class Engine:
         if toks is not None:
             first_tokens, first_lps = toks.cpu().numpy(), lps.cpu().numpy()
         if logits is not None:
-            # decisions / scores at the prompt's last position
+            # decisions / scores at the prompt's last position: one gather over all rows that
+            # need one (target lists padded to a common width), one read-back
+            want = []   # (logits row, request state, target ids)
             for j, seq_i in enumerate(plan.last_row_seq):
-                rid = int(req_ids[int(seq_i)])
-                st = self._reqs[rid]
-                row = torch.tensor([j], dtype=torch.int32, device=self.device)
+                st = self._reqs[int(req_ids[int(seq_i)])]
                 if st.kind == core.RequestKind.Score and st.score_ids:
-                    ids = torch.tensor(st.score_ids, dtype=torch.int32, device=self.device)
-                    st.scores = ops.logprob_gather(logits, ids, row)[0].cpu().tolist()
+                    want.append((j, st, st.score_ids))
                 elif st.kind == core.RequestKind.Generate and st.decision_ids:
-                    ids = torch.tensor(st.decision_ids, dtype=torch.int32, device=self.device)
-                    d = ops.logprob_gather(logits, ids, row)[0].cpu().tolist()
-                    for k in range(st.n):
-                        st.decisions[st.seed + k] = d
+                    want.append((j, st, st.decision_ids))
+            if want:
+                width = max(len(ids) for _, _, ids in want)
+                ids_h = np.zeros((len(want), width), dtype=np.int32)
+                for i, (_, _, ids) in enumerate(want):
+                    ids_h[i, : len(ids)] = ids
+                rows = self._dev(np.array([j for j, _, _ in want], dtype=np.int32))
+                vals = ops.logprob_gather(logits, self._dev(ids_h), rows).cpu().numpy()
+                for i, (_, st, ids) in enumerate(want):
+                    v = vals[i, : len(ids)].tolist()
+                    if st.kind == core.RequestKind.Score:
+                        st.scores = v
+                    else:
+                        for k in range(st.n):
+                            st.decisions[st.seed + k] = v
         self.sched.complete_prefill(plan, first_tokens.astype(np.int32), first_lps.astype(np.float32))
 
     def _bucket(self, B: int) -> int:
