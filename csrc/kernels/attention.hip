@@ -52,31 +52,47 @@ LC_DEVICE void process_tile(AttnState<DH>& st, const bf16x8 (&qf)[DH / 16], cons
     sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[kk], qf[kk], sc, 0, 0, 0);
 
   // ---- online softmax (row q = lane&31; this lane holds keys k0 + 16*(reg>>3) + 8h + (reg&7)) ----
+  // Only tiles that straddle a row's visibility bounds (the causal diagonal, a sliding-window
+  // edge, the ragged tail) need per-key masks; the test is wave-uniform.
+  const bool interior = __all(k0 >= lo_q && k0 + 32 <= hi_q);
   float tmax = kNegBig;
-  bool vis[16];
+  if (interior) {
 #pragma unroll
-  for (int g = 0; g < 16; ++g) {
-    const int kidx = k0 + 16 * (g >> 3) + 8 * h + (g & 7);
-    vis[g] = (kidx >= lo_q) && (kidx < hi_q);
-    sc[g] = vis[g] ? sc[g] * scale2 : kNegBig;
-    tmax = fmaxf(tmax, sc[g]);
+    for (int g = 0; g < 16; ++g) {
+      sc[g] *= scale2;
+      tmax = fmaxf(tmax, sc[g]);
+    }
+  } else {
+#pragma unroll
+    for (int g = 0; g < 16; ++g) {
+      const int kidx = k0 + 16 * (g >> 3) + 8 * h + (g & 7);
+      sc[g] = (kidx >= lo_q && kidx < hi_q) ? sc[g] * scale2 : kNegBig;
+      tmax = fmaxf(tmax, sc[g]);
+    }
   }
   tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
   const float m_new = fmaxf(st.m, tmax);
-  const float alpha = exp2f(st.m - m_new);
-  st.m = m_new;
+  // Rescaling the accumulators costs Dh/2 multiplies per lane; once the running maxima have
+  // settled (no lane's maximum moved) it is skipped for the whole wave.
+  if (__any(m_new > st.m)) {
+    const float alpha = fast_exp2(st.m - m_new);
+    st.l *= alpha;
+#pragma unroll
+    for (int b = 0; b < DH / 32; ++b)
+#pragma unroll
+      for (int g = 0; g < 16; ++g) st.o[b][g] *= alpha;
+    st.m = m_new;
+  }
   float psum = 0.f;
 #pragma unroll
   for (int g = 0; g < 16; ++g) {
-    const float p = vis[g] ? exp2f(sc[g] - m_new) : 0.f;
+    // masked scores sit at kNegBig: 2^(kNegBig - m) is 0 unless the whole row is still masked
+    // (m == kNegBig), which the explicit test covers
+    const float p = sc[g] > 0.5f * kNegBig ? fast_exp2(sc[g] - st.m) : 0.f;
     sc[g] = p;
     psum += p;
   }
-  st.l = st.l * alpha + psum;
-#pragma unroll
-  for (int b = 0; b < DH / 32; ++b)
-#pragma unroll
-    for (int g = 0; g < 16; ++g) st.o[b][g] *= alpha;
+  st.l += psum;
 
   // ---- O^T += Vt * P^T ----
   bf16x8 pf[2];
@@ -174,51 +190,11 @@ LC_DEVICE void finish_and_store(AttnState<DH>& st, bf16_t* out_bf16, float* out_
 }
 
 // ------------------------------------------------------------------ prefill
-// grid (q_tile, kv_head, seq); block = G waves (G = Hq/Hkv), wave g = q-head kvh*G+g.
-template <int DH>
-__global__ __launch_bounds__(512) void attn_prefill_kernel(const bf16_t* __restrict__ Q, int q_stride,
-                                    const bf16_t* __restrict__ Kc, const bf16_t* __restrict__ Vt,
-                                    const int32_t* __restrict__ block_tables, int max_blocks,
-                                    const int32_t* __restrict__ cu_q, const int32_t* __restrict__ ctx_lens,
-                                    bf16_t* __restrict__ out, int Hq, int Hkv, int lbs, float scale2,
-                                    int window) {
-  const int s = blockIdx.z, kvh = blockIdx.y, tile = blockIdx.x;
-  const int q0 = cu_q[s], q_len = cu_q[s + 1] - q0;
-  if (tile * 32 >= q_len) return;
-  const int lane = threadIdx.x & 63;
-  const int g = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int G = Hq / Hkv;
-  const int head = kvh * G + g;
-  const int ctx = ctx_lens[s];
-  const int base_pos = ctx - q_len;
-  const int i = tile * 32 + (lane & 31);
-  const bool valid = i < q_len;
-  const int pos = base_pos + i;
-  const int hi_q = valid ? pos + 1 : 0;
-  const int lo_q = (valid && window > 0 && pos + 1 > window) ? pos + 1 - window : 0;
-
-  bf16x8 qf[DH / 16];
-  load_q<DH>(qf, valid ? Q + static_cast<size_t>(q0 + i) * q_stride + head * DH : nullptr, lane);
-  TileCtx c{Kc, Vt, block_tables + static_cast<size_t>(s) * max_blocks, Hkv, kvh, lbs, 1 << lbs, scale2};
-  AttnState<DH> st;
-  init_state<DH>(st);
-  const int last_row = min(tile * 32 + 31, q_len - 1);
-  const int kv_hi = base_pos + last_row + 1;
-  int kv_lo = 0;
-  if (window > 0) {
-    const int first_pos = base_pos + tile * 32;
-    kv_lo = first_pos + 1 > window ? first_pos + 1 - window : 0;
-  }
-  attend_range<DH>(st, qf, c, kv_lo, kv_hi, lo_q, hi_q, lane);
-  bf16_t* orow = valid ? out + static_cast<size_t>(q0 + i) * (Hq * DH) + head * DH : nullptr;
-  finish_and_store<DH>(st, orow, nullptr, nullptr, lane);
-}
-
-// ------------------------------------------------------------------ prefill, K/V through LDS
-// Same work split (grid (q_tile, kv_head, seq); the G waves of a workgroup are the G query heads
-// that share the kv head, 32 query rows each), but the 32-key K/V tiles are staged ONCE per
-// workgroup in LDS by LDS-DMA and every wave reads its MFMA fragments from there, instead of
-// each wave pulling the same 16 KiB per tile through the vector L1. A ring of PF_NSTAGE
+// grid (q_tile, kv_head x ceil(G/4), seq); a workgroup is 4 waves = up to 4 of the G query heads
+// that share a kv head, 32 query rows each (256 threads leave each wave the ~180 VGPRs a
+// Dh = 128 tile needs). The 32-key K/V tiles are staged ONCE per workgroup in LDS by LDS-DMA
+// and every wave reads its MFMA fragments from there, instead of each wave pulling the same
+// 16 KiB per tile through the vector L1. A ring of PF_NSTAGE
 // stages keeps two tiles in flight; one barrier per tile does both jobs of the ring (tile t
 // visible to all, tile t-1 released), exactly as in gemm_panel.hip.
 //
@@ -240,24 +216,26 @@ struct PrefillLds {
 };
 
 template <int DH>
-__global__ __launch_bounds__(512) void attn_prefill_lds_kernel(
+__global__ __launch_bounds__(256, 2) void attn_prefill_lds_kernel(
     const bf16_t* __restrict__ Q, int q_stride, const bf16_t* __restrict__ Kc, const bf16_t* __restrict__ Vt,
     const int32_t* __restrict__ block_tables, int max_blocks, const int32_t* __restrict__ cu_q,
     const int32_t* __restrict__ ctx_lens, bf16_t* __restrict__ out, int Hq, int Hkv, int lbs, float scale2,
-    int window, int ppw) {
+    int window) {
   using L = PrefillLds<DH>;
+  constexpr int PPW = L::PIECES / 4;   // DMA instructions per wave per tile
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int s = blockIdx.z, kvh = blockIdx.y, tile = blockIdx.x;
+  const int G = Hq / Hkv, nsub = (G + 3) / 4;
+  const int s = blockIdx.z, kvh = blockIdx.y / nsub, sub = blockIdx.y % nsub, tile = blockIdx.x;
   const int q0 = cu_q[s], q_len = cu_q[s + 1] - q0;
   if (tile * 32 >= q_len) return;
   const int lane = threadIdx.x & 63;
   const int g = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int G = Hq / Hkv;
-  const int head = kvh * G + g;
+  const bool has_head = sub * 4 + g < G;   // a wave without a head still moves its share of K/V
+  const int head = kvh * G + min(sub * 4 + g, G - 1);
   const int ctx = ctx_lens[s];
   const int base_pos = ctx - q_len;
   const int i = tile * 32 + (lane & 31);
-  const bool valid = i < q_len;
+  const bool valid = has_head && i < q_len;
   const int pos = base_pos + i;
   const int hi_q = valid ? pos + 1 : 0;
   const int lo_q = (valid && window > 0 && pos + 1 > window) ? pos + 1 - window : 0;
@@ -279,19 +257,25 @@ __global__ __launch_bounds__(512) void attn_prefill_lds_kernel(
   }
   const int t_lo = kv_lo >> 5, nt = ((kv_hi + 31) >> 5) - t_lo;   // 32-key tiles [t_lo, t_lo + nt)
 
-  // Every wave issues `ppw` pieces per tile (pieces beyond L::PIECES wrap around: a duplicate
-  // write of the same bytes), so all waves count the same number of loads.
+  // The block-table entries this workgroup needs go to LDS first. Looking them up in global
+  // memory while tiles are in flight would make every DMA address wait on vmcnt(0) -- i.e.
+  // drain the ring once per piece; LDS reads are counted separately (lgkmcnt).
+  int32_t* bt_s = reinterpret_cast<int32_t*>(smem + PF_NSTAGE * L::STAGE);
+  for (int b = threadIdx.x; b <= ((kv_hi - 1) >> lbs); b += 256) bt_s[b] = bt[b];
+  __syncthreads();
+
   auto issue_tile = [&](int t) {
     if (t >= nt) return;
     char* stage = smem + (t % PF_NSTAGE) * L::STAGE;
     const int k0 = (t_lo + t) << 5;
-    for (int q = 0; q < ppw; ++q) {
-      const int piece = (q * G + g) % L::PIECES;
+#pragma unroll
+    for (int q = 0; q < PPW; ++q) {
+      const int piece = q * 4 + g;
       if (piece < L::K_PIECES) {
         const int kl = piece * L::KEYS_PER_PIECE + lane / L::CH, lc = lane % L::CH;   // key in tile, position
         int key = k0 + kl;
         key = key < kv_hi ? key : kv_hi - 1;
-        const bf16_t* src = Kc + static_cast<size_t>(bt[key >> lbs]) * kblk_stride +
+        const bf16_t* src = Kc + static_cast<size_t>(bt_s[key >> lbs]) * kblk_stride +
                             (static_cast<size_t>(kvh) * BS + (key & (BS - 1))) * DH + ((lc ^ (kl & (L::CH - 1))) << 3);
         __builtin_amdgcn_global_load_lds(LC_GLOBAL_PTR(src), LC_LDS_PTR(stage + piece * 1024), 16, 0, 0);
       } else {
@@ -300,18 +284,15 @@ __global__ __launch_bounds__(512) void attn_prefill_lds_kernel(
         int key8 = k0 + 8 * (lc ^ ((d >> 2) & 3));
         const int last8 = (kv_hi - 1) & ~7;
         key8 = key8 < kv_hi ? key8 : last8;
-        const bf16_t* src = Vt + static_cast<size_t>(bt[key8 >> lbs]) * kblk_stride +
+        const bf16_t* src = Vt + static_cast<size_t>(bt_s[key8 >> lbs]) * kblk_stride +
                             (static_cast<size_t>(kvh) * DH + d) * BS + (key8 & (BS - 1));
         __builtin_amdgcn_global_load_lds(LC_GLOBAL_PTR(src), LC_LDS_PTR(stage + L::K_BYTES + vp * 1024), 16, 0, 0);
       }
     }
   };
-  auto wait_in_flight = [&](int tiles) {   // ppw is 1..4 and at most one tile stays in flight
+  auto wait_in_flight = [&](int tiles) {   // at most one tile stays in flight
     if (tiles == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    else if (ppw == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
-    else if (ppw == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-    else if (ppw == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW) : "memory");
   };
 
   const int r = lane & 31, h = lane >> 5;
@@ -560,31 +541,21 @@ LC_EXPORT int lc_attn_prefill(const void* Q, int q_stride, const void* Kc, const
                               const void* ctx_lens, void* out, int n_seqs, int max_q_len, int Hq, int Hkv,
                               int Dh, int block_size, float scale, int window, hipStream_t stream) {
   if (n_seqs <= 0 || max_q_len <= 0) return 0;
-  if (Hq % Hkv || Hq / Hkv > 8 || (Dh != 64 && Dh != 128) || block_size % 8 ||
-      (block_size & (block_size - 1)))
-    return -1;
-  const dim3 grid((max_q_len + 31) / 32, Hkv, n_seqs), block(64 * (Hq / Hkv));
+  if (Hq % Hkv || (Dh != 64 && Dh != 128) || block_size % 8 || (block_size & (block_size - 1))) return -1;
+  const int G = Hq / Hkv;
+  const dim3 grid((max_q_len + 31) / 32, Hkv * ((G + 3) / 4), n_seqs), block(256);
   const float scale2 = scale * 1.4426950408889634f;
   const int lbs = ilog2(block_size);
 #define LC_ARGS                                                                                          \
   static_cast<const bf16_t*>(Q), q_stride, static_cast<const bf16_t*>(Kc), static_cast<const bf16_t*>(Vt), \
       static_cast<const int32_t*>(block_tables), max_blocks, static_cast<const int32_t*>(cu_q),          \
       static_cast<const int32_t*>(ctx_lens), static_cast<bf16_t*>(out), Hq, Hkv, lbs, scale2, window
-  // K/V through LDS when the G waves of a workgroup can move a tile with at most 4 DMA
-  // instructions each (G >= 4 at Dh = 128, G >= 2 at Dh = 64); otherwise straight to registers.
-  const int G = Hq / Hkv;
-  const int pieces = Dh == 128 ? PrefillLds<128>::PIECES : PrefillLds<64>::PIECES;
-  const int ppw = (pieces + G - 1) / G;
-  if (ppw <= 4) {
-    if (Dh == 128)
-      attn_prefill_lds_kernel<128><<<grid, block, PF_NSTAGE * PrefillLds<128>::STAGE, stream>>>(LC_ARGS, ppw);
-    else
-      attn_prefill_lds_kernel<64><<<grid, block, PF_NSTAGE * PrefillLds<64>::STAGE, stream>>>(LC_ARGS, ppw);
-  } else if (Dh == 128) {
-    attn_prefill_kernel<128><<<grid, block, 0, stream>>>(LC_ARGS);
-  } else {
-    attn_prefill_kernel<64><<<grid, block, 0, stream>>>(LC_ARGS);
-  }
+  if (max_blocks > 8192) return -1;   // the block-table slice kept in LDS
+  const size_t bt_bytes = static_cast<size_t>(max_blocks) * sizeof(int32_t);
+  if (Dh == 128)
+    attn_prefill_lds_kernel<128><<<grid, block, PF_NSTAGE * PrefillLds<128>::STAGE + bt_bytes, stream>>>(LC_ARGS);
+  else
+    attn_prefill_lds_kernel<64><<<grid, block, PF_NSTAGE * PrefillLds<64>::STAGE + bt_bytes, stream>>>(LC_ARGS);
 #undef LC_ARGS
   LC_RETURN_LAST_ERROR();
 }

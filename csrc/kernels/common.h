@@ -26,17 +26,20 @@ typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
 
 LC_DEVICE float bf16_to_f32(bf16_t h) { return __uint_as_float(static_cast<uint32_t>(h) << 16); }
 
-// Round-to-nearest-even; NaN stays NaN.
-LC_DEVICE bf16_t f32_to_bf16(float f) {
-  uint32_t u = __float_as_uint(f);
-  if ((u & 0x7fffffffu) > 0x7f800000u) return static_cast<bf16_t>((u >> 16) | 0x40);
-  u += 0x7fffu + ((u >> 16) & 1u);
-  return static_cast<bf16_t>(u >> 16);
+typedef __attribute__((ext_vector_type(2))) __bf16 lc_bf16v2;
+typedef __attribute__((ext_vector_type(2))) float lc_f32v2;
+
+// fp32 -> bf16, round-to-nearest-even, in hardware (v_cvt_pk_bf16_f32 converts two at a time).
+LC_DEVICE uint32_t pack_bf16x2(float lo, float hi) {
+  const lc_f32v2 v = {lo, hi};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, lc_bf16v2));
 }
 
-LC_DEVICE uint32_t pack_bf16x2(float lo, float hi) {
-  return static_cast<uint32_t>(f32_to_bf16(lo)) | (static_cast<uint32_t>(f32_to_bf16(hi)) << 16);
-}
+LC_DEVICE bf16_t f32_to_bf16(float f) { return static_cast<bf16_t>(pack_bf16x2(f, 0.f) & 0xffffu); }
+
+// 2^x as the bare v_exp_f32 (no denormal-range fix-up: results below 2^-126 flush to zero,
+// which is what a softmax weight that small should do anyway).
+LC_DEVICE float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 
 LC_DEVICE float wave_sum(float v) {
 #pragma unroll
