@@ -117,11 +117,21 @@ LC_DEVICE void attend_range(AttnState<DH>& st, const bf16x8 (&qf)[DH / 16], cons
   const int r = lane & 31, h = lane >> 5;
   const int pi_r = (r & ~0xC) | ((r & 4) << 1) | ((r & 8) >> 1);
   const size_t kblk_stride = static_cast<size_t>(c.Hkv) * c.BS * DH;
+  // Block-table entries live in a VGPR (lane i holds entry blk_base + i) and are fetched by
+  // lane shuffle: looking them up in memory per tile would put a second dependent global
+  // round trip in front of every K/V load. Reloaded every 64 blocks.
+  const int last_blk = (kv_hi - 1) >> c.lbs;
+  int blk_base = (kv_lo & ~31) >> c.lbs;
+  int btv = c.bt[min(blk_base + lane, last_blk)];
   for (int k0 = kv_lo & ~31; k0 < kv_hi; k0 += 32) {
+    if (((k0 + 31) >> c.lbs) - blk_base > 63) {
+      blk_base = k0 >> c.lbs;
+      btv = c.bt[min(blk_base + lane, last_blk)];
+    }
     // ---- S^T = K * Q^T ----
     int key = k0 + pi_r;
     key = key < kv_hi ? key : kv_hi - 1;
-    const bf16_t* kp = c.Kc + static_cast<size_t>(c.bt[key >> c.lbs]) * kblk_stride +
+    const bf16_t* kp = c.Kc + static_cast<size_t>(__shfl(btv, (key >> c.lbs) - blk_base, 64)) * kblk_stride +
                        (static_cast<size_t>(c.kvh) * c.BS + (key & (c.BS - 1))) * DH + 8 * h;
     bf16x8 kf[DH / 16];
 #pragma unroll
@@ -133,7 +143,7 @@ LC_DEVICE void attend_range(AttnState<DH>& st, const bf16x8 (&qf)[DH / 16], cons
       int key8 = k0 + 16 * s + 8 * h;
       const int last8 = (kv_hi - 1) & ~7;
       key8 = key8 < kv_hi ? key8 : last8;
-      const bf16_t* vp = c.Vt + static_cast<size_t>(c.bt[key8 >> c.lbs]) * kblk_stride +
+      const bf16_t* vp = c.Vt + static_cast<size_t>(__shfl(btv, (key8 >> c.lbs) - blk_base, 64)) * kblk_stride +
                          (static_cast<size_t>(c.kvh) * DH + r) * c.BS + (key8 & (c.BS - 1));
 #pragma unroll
       for (int b = 0; b < DH / 32; ++b)
