@@ -26,6 +26,8 @@ from ..utils.trace import span
 
 log = get_logger("consensus.engine")
 PK = core.StepPlan.Kind
+# One member engine prefills at a time while the others decode (see run_engines).
+STAGGER_PREFILL = os.environ.get("CONSENSUS_STAGGER_PREFILL", "1") == "1"
 
 
 def serialize_streams() -> bool:
@@ -240,9 +242,16 @@ class Engine:
     def begin_step(self):
         """Schedules one step and enqueues its GPU work on the engine's stream without waiting
         for it. Returns an opaque token for ``end_step`` (None when idle)."""
+        plan = self.plan_step()
+        return None if plan is None else self.launch_step(plan)
+
+    def plan_step(self):
+        """Asks the scheduler for the next step without launching it (None when idle). The plan
+        may be held back by a driver and launched later with ``launch_step``."""
         plan = self.sched.schedule()
-        if plan.kind == PK.Idle:
-            return None
+        return None if plan.kind == PK.Idle else plan
+
+    def launch_step(self, plan):
         t0 = time.perf_counter()
         with self._on_stream():
             if len(plan.copy_src):
@@ -254,11 +263,20 @@ class Engine:
             else:
                 with span(f"{self.name}.decode", "engine", seqs=len(plan.seq_ids)):
                     state = self._decode_launch(plan)
-        return plan, state, t0
+            done = None
+            if self.stream is not None:
+                done = torch.cuda.Event()
+                done.record(self.stream)
+        return plan, state, t0, done
+
+    @staticmethod
+    def step_done(token) -> bool:
+        """True once the GPU work of a launched step has finished (``end_step`` will not block)."""
+        return token[3] is None or token[3].query()
 
     def end_step(self, token) -> None:
         """Waits for the step started by ``begin_step`` and does its bookkeeping."""
-        plan, state, t0 = token
+        plan, state, t0, _ = token
         with self._on_stream():
             if plan.kind == PK.Prefill:
                 self._prefill_finish(plan, state)
@@ -526,14 +544,38 @@ def run_engines(engines: Sequence["Engine"]) -> None:
         for e in live:
             e.run_until_done()
         return
-    pending = {}
+    # Prefill steps are MFMA-bound, decode steps HBM-bound. With STAGGER_PREFILL only one engine
+    # prefills at a time, so the others' decode steps run against a prefill instead of against
+    # each other's prefills: the chip then has compute-bound and memory-bound kernels in flight
+    # together. An engine whose next step is a prefill simply holds its plan until the slot frees.
+    pending, held = {}, {}
+    prefilling = None          # the engine that owns the prefill slot
     while live:
+        progressed = False
         for e in list(live):
-            tok = pending.pop(e, None)
+            tok = pending.get(e)
             if tok is not None:
+                # Never block on one engine's long prefill while another's decode step is done.
+                if STAGGER_PREFILL and len(pending) > 1 and not e.step_done(tok):
+                    continue
+                del pending[e]
                 e.end_step(tok)
-            tok = e.begin_step()
-            if tok is None:
+                progressed = True
+                if prefilling is e:
+                    prefilling = None
+            plan = held.pop(e, None) or e.plan_step()
+            if plan is None:
                 live.remove(e)
+                continue
+            if STAGGER_PREFILL and plan.kind == PK.Prefill:
+                if prefilling is not None and prefilling is not e:
+                    held[e] = plan
+                    continue
+                prefilling = e
+            pending[e] = e.launch_step(plan)
+            progressed = True
+        if not progressed:
+            if not pending:
+                prefilling = None   # nothing in flight: never leave every engine waiting on a stale slot
             else:
-                pending[e] = tok
+                time.sleep(20e-6)
