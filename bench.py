@@ -51,6 +51,9 @@ def parse_args():
     ap.add_argument("--sc-questions", type=int, default=16, help="questions per GPU per step (workload B)")
     ap.add_argument("--sc-steps", type=int, default=None, help="timed steps of workload B (default: --steps)")
     ap.add_argument("--skip-self-consistency", action="store_true")
+    ap.add_argument("--proto-questions", type=int, default=8,
+                    help="questions per GPU per step of the reference-protocol workload (0 = skip)")
+    ap.add_argument("--proto-prompt-len", type=int, default=128)
     ap.add_argument("--temperature", type=float, default=0.8)
     ap.add_argument("--top-p", type=float, default=0.95)
     ap.add_argument("--no-graphs", action="store_true")
@@ -127,19 +130,21 @@ def main() -> None:
         """Cross-GPU gather of the per-question winners (class ids) to every rank."""
         return gather_winners(comm, results, "ABCD", dev)
 
-    def run_phase(strategy, n_q, steps, warmup):
+    def run_phase(strategy, n_q, steps, warmup, prompt_len=a.prompt_len, gather=gather_answers, keep=None):
         lat = []
         for _ in range(warmup):
-            gather_answers(strategy.ask_many(make_questions(rng, n_q, a.prompt_len)))
+            gather(strategy.ask_many(make_questions(rng, n_q, prompt_len)))
         comm.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         n_ans = 0
         for _ in range(steps):
-            res = strategy.ask_many(make_questions(rng, n_q, a.prompt_len))
-            allw = gather_answers(res)
+            res = strategy.ask_many(make_questions(rng, n_q, prompt_len))
+            allw = gather(res)
             n_ans += int(allw.numel())
             lat += [r.latency_s * 1e3 for r in res]
+            if keep is not None:
+                keep.extend(res)
         torch.cuda.synchronize()
         comm.barrier()
         el = comm.max_float(time.perf_counter() - t0)
@@ -193,6 +198,56 @@ def main() -> None:
             "prefix_cache_hit_rate": round(float(st.get("kv.prefix_hit_rate", 0.0)), 3),
             "cow_copies": int(st.get("kv.cow_copies_total", 0)),
         }
+    if a.proto_questions > 0:
+        # The reference's own topology and loop: four personas share ONE model, a random member
+        # proposes, everyone (proposer included) judges, a random dissenter refines, at most five
+        # evaluation rounds (/root/reference/src/main.rs:220-311, 359-426). Verdicts are the
+        # on-device two-way log-prob decision because random-init weights never spell a verdict.
+        from llm_consensus_amd.consensus.protocol import Coordinator
+
+        model0 = members[0].backend.engine.model
+        plen = 2048 + 2 * a.proto_prompt_len + 2 * a.new_tokens        # evaluate prompt: template + question + answer
+        n_seq = a.proto_questions * 4
+        eng_p = Engine(model0, num_kv_blocks=(n_seq + 4) * ((plen + bs - 1) // bs + 1) + 64, block_size=bs,
+                       max_batch_seqs=max(64, n_seq), max_prefill_tokens=8192, max_model_len=plen,
+                       use_graphs=not a.no_graphs, name=names[0] + ".panel")
+        be_p = EngineBackend(eng_p, ByteLevelTokenizer(model0.cfg.vocab_size), stop_at_eos=False)
+        gp_p = GenParams(temperature=a.temperature, top_p=a.top_p, max_new_tokens=a.new_tokens, seed=99)
+        def count_answers(results):
+            # Answers are free text here; ranks exchange one row per finished question.
+            done = torch.tensor([[int(r.forced)] for r in results], dtype=torch.int32, device=dev)
+            return comm.all_gather_rows(done)
+
+        # Two prompt layouts: the reference's (domain named a third of the way into the evaluate
+        # prompt) and the same instructions with the persona text moved to the end, which lets
+        # the four evaluate prompts of a round share most of their prefill.
+        for key, templates in (("reference_protocol", core.PromptTemplates()),
+                               ("reference_protocol_persona_last", core.PromptTemplates.persona_last())):
+            panel = [Member(p, be_p, templates, gp_p, decision_mode="logprob") for p in personas[:4]]
+            sess = core.SessionConfig()
+            sess.max_rounds, sess.seed = 5, 4242 + rank
+            coord = Coordinator(panel, sess)
+            kept = []
+            st0 = be_p.stats()
+            el_p, n_p, lat_p = run_phase(coord, a.proto_questions, a.steps, a.warmup, a.proto_prompt_len,
+                                         count_answers, kept)
+            lat_p_all = comm.gather_floats(lat_p)
+            st = be_p.stats()
+            hit = (st["kv.prefix_hit_tokens"] - st0["kv.prefix_hit_tokens"]) / max(1, st["kv.prompt_tokens"] - st0["kv.prompt_tokens"])
+            out[key] = {
+                "metric": f"consensus answers/sec, reference protocol (4 personas on {names[0]}, unanimity loop, <= 5 rounds)",
+                "value": round(n_p / el_p, 3),
+                "ms_per_step": round(el_p / a.steps * 1e3, 2),
+                "steps": a.steps,
+                "questions_per_gpu": a.proto_questions,
+                "question_tokens": a.proto_prompt_len,
+                "p50_latency_ms": round(float(np.percentile(lat_p_all, 50)), 1),
+                "p95_latency_ms": round(float(np.percentile(lat_p_all, 95)), 1),
+                "mean_rounds": round(float(np.mean([r.rounds for r in kept])), 2),
+                "mean_member_calls": round(float(np.mean([r.member_calls for r in kept])), 2),
+                "forced_fraction": round(float(np.mean([r.forced for r in kept])), 3),
+                "prefix_cache_hit_rate": round(float(hit), 3),
+            }
     if rank == 0:
         line = json.dumps(out)
         print(line, flush=True)

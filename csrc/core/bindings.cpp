@@ -63,6 +63,7 @@ PYBIND11_MODULE(_core, m) {
   m.def("default_personas", &default_personas);
   py::class_<PromptTemplates>(m, "PromptTemplates")
       .def(py::init(&PromptTemplates::defaults))
+      .def_static("persona_last", &PromptTemplates::persona_last)
       .def_readwrite("propose", &PromptTemplates::propose)
       .def_readwrite("evaluate", &PromptTemplates::evaluate)
       .def_readwrite("refine", &PromptTemplates::refine)
@@ -210,6 +211,9 @@ PYBIND11_MODULE(_core, m) {
       .def("reserve", &KVManager::reserve)
       .def("commit", [](KVManager& kv, int seq, i32arr tokens) {
         kv.commit(seq, tokens.data(), static_cast<int>(tokens.size()));
+      })
+      .def("extend_match", [](KVManager& kv, int seq, i32arr tokens) {
+        return kv.extend_match(seq, tokens.data(), static_cast<int>(tokens.size()));
       })
       .def("fork", &KVManager::fork)
       .def("free_sequence", &KVManager::free_sequence)

@@ -117,6 +117,32 @@ int KVManager::create_sequence(const int32_t* tokens, int n, int* cached_tokens,
   return id;
 }
 
+int KVManager::extend_match(int seq, const int32_t* tokens, int n) {
+  if (!prefix_cache_) return 0;
+  Seq& s = seqs_.at(seq);
+  int b = s.num_tokens / block_size_;
+  if (s.num_tokens % block_size_ != 0 || !s.tail.empty() || static_cast<int>(s.chain.size()) != b) return 0;
+  const int max_match = (n - 1) / block_size_;   // leave at least one token to run
+  uint64_t prev = s.chain.empty() ? 0 : s.chain.back();
+  int added = 0;
+  for (; b < max_match && b < static_cast<int>(s.blocks.size()); ++b) {
+    uint64_t h = hash_block(prev, tokens + static_cast<size_t>(b) * block_size_, block_size_);
+    auto it = cache_.find(h);
+    if (it == cache_.end()) break;
+    if (it->second != s.blocks[b]) {
+      alloc_.incref(it->second);
+      alloc_.decref(s.blocks[b]);   // never written, never cached: goes back to the free list
+      s.blocks[b] = it->second;
+    }
+    s.chain.push_back(h);
+    prev = h;
+    s.num_tokens += block_size_;
+    ++added;
+  }
+  stats_.prefix_hit_tokens += static_cast<int64_t>(added) * block_size_;
+  return added * block_size_;
+}
+
 bool KVManager::reserve(int seq, int n_new) {
   Seq& s = seqs_.at(seq);
   // Copy-on-write of a shared, partially filled tail block.

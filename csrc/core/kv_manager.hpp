@@ -57,6 +57,12 @@ class KVManager {
   // hidden state of every prompt token, e.g. embeddings).
   int create_sequence(const int32_t* tokens, int n, int* cached_tokens, bool allow_cache_hit = true);
 
+  // Second chance at the prefix cache for a sequence that has not computed anything of its
+  // own yet: blocks registered since create_sequence (for instance by a prompt scheduled
+  // earlier in the same prefill step) replace the sequence's unwritten blocks. Returns the
+  // number of additional leading tokens that now have KV.
+  int extend_match(int seq, const int32_t* tokens, int n);
+
   // Ensures the sequence has room for `n_new` more tokens, allocating blocks and
   // queueing a copy-on-write if its partially filled tail block is shared.
   bool reserve(int seq, int n_new);

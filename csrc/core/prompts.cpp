@@ -92,6 +92,37 @@ PromptTemplates PromptTemplates::defaults() {
   return t;
 }
 
+PromptTemplates PromptTemplates::persona_last() {
+  PromptTemplates t = defaults();
+  t.evaluate =
+      "\n---\nQuestion: {question}\n---\nAnswer: {answer}\n---\nYour Instructions:\n"
+      "You belong to a panel of LLMs that must agree on an answer to the question above. "
+      "The answer shown came from the first panel member chosen. Judge that answer from the "
+      "point of view of your knowledge domain, which is named at the end of these instructions. "
+      "You may reply with only one of two verdicts: Good or NeedsRefinement.\n\n"
+      "A direct link between the answer and your domain is not required; think about indirect "
+      "or tangential links too, and about how the answer could enable, inspire or be used in "
+      "work belonging to your domain.\n\n"
+      "First decide whether the question has anything to do with your domain. If it does not, "
+      "you are not qualified to judge, so reply with exactly Good. If it does and you find the "
+      "answer good, reply with exactly Good. If you find the answer bad, reply with exactly "
+      "NeedsRefinement. Then, on a new line, give the reasoning behind your verdict.\n"
+      "---\nExamples:\n\n"
+      "Question: Which programming language suits a beginner?\n"
+      "Answer: Python\n"
+      "Your domain: art and imagination\n"
+      "Evaluation: Good\n"
+      "Reasoning: The question is outside your domain.\n\n"
+      "Question: What makes software simpler to update?\n"
+      "Answer: Decoupling\n"
+      "Your domain: technical rigor\n"
+      "Evaluation: NeedsRefinement\n"
+      "Reasoning: Loose coupling is only one ingredient of maintainable software and the "
+      "answer gives too little detail.\n"
+      "---\nYour knowledge domain: {domain}. In particular keep these aspects in mind:{tuning}";
+  return t;
+}
+
 namespace {
 
 // Single-pass substitution so that text inserted for one placeholder is never

@@ -34,6 +34,12 @@ struct PromptTemplates {
   std::string refine;    // placeholders: {question} {answer} {domain} {tuning} {reasoning}
   bool strip_quotes = true;
   static PromptTemplates defaults();
+  // Same instructions with everything that depends on the persona moved to the END of the
+  // evaluate prompt (the reference names the domain a third of the way in, main.rs:118, and
+  // lists the tuning bullets before the verdict rules and examples, main.rs:120). With N
+  // personas on one model the rules and examples are then prefilled once per answer instead
+  // of N times: the shared prefix grows from roughly a quarter of the prompt to four fifths.
+  static PromptTemplates persona_last();
 };
 
 std::string render_propose(const PromptTemplates& t, const std::string& question);

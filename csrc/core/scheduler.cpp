@@ -105,9 +105,17 @@ StepPlan Scheduler::schedule() {
       if (budget <= 0) break;
       Group& g = groups_.at(gid);
       const int P = static_cast<int>(g.prompt.size());
+      const int seq = g.chains[0].seq;
+      if (g.computed == g.cached && g.kind != RequestKind::Embed) {
+        // Prompts admitted together looked the prefix cache up before any of them had run.
+        // Blocks of the prompts placed earlier in this very step are registered by now (the
+        // step writes their KV before any attention reads it), so look again.
+        const int more = kv_->extend_match(seq, g.prompt.data(), P);
+        g.cached += more;
+        g.computed += more;
+      }
       const int take = std::min(P - g.computed, budget);
       if (take <= 0) continue;
-      const int seq = g.chains[0].seq;
       const auto& bt = kv_->block_table(seq);
       const int row0 = static_cast<int>(plan.token_ids.size());
       for (int i = 0; i < take; ++i) {
@@ -120,6 +128,9 @@ StepPlan Scheduler::schedule() {
       plan.request_ids.push_back(gid);
       plan.context_lens.push_back(g.computed + take);
       plan.cu_q.push_back(row0 + take);
+      // Registered now rather than on completion: steps of one engine execute in order, so
+      // whoever finds these blocks in the prefix cache reads them after this step wrote them.
+      kv_->commit(seq, g.prompt.data() + g.computed, take);
       if (g.computed + take == P) {
         plan.last_rows.push_back(row0 + take - 1);
         plan.last_row_seq.push_back(static_cast<int>(plan.seq_ids.size()) - 1);
@@ -247,7 +258,6 @@ void Scheduler::complete_prefill(const StepPlan& plan, const int32_t* first_toke
     const int gid = plan.request_ids[i];
     Group& g = groups_.at(gid);
     const int take = plan.cu_q[i + 1] - plan.cu_q[i];
-    kv_->commit(g.chains[0].seq, g.prompt.data() + g.computed, take);
     g.computed += take;
     const bool ends = last_j < plan.last_row_seq.size() && plan.last_row_seq[last_j] == static_cast<int>(i);
     if (!ends) continue;

@@ -89,6 +89,7 @@ class ConsensusConfig:
     sampling: SamplingConfig = field(default_factory=SamplingConfig)
     models: Dict[str, ModelSpec] = field(default_factory=lambda: {"default": ModelSpec()})
     members: List[MemberConfig] = field(default_factory=list)
+    prompt_layout: str = "reference"       # reference | persona_last (persona text at the end: longer shared prefix)
     prompt_propose: Optional[str] = None   # template file paths
     prompt_evaluate: Optional[str] = None
     prompt_refine: Optional[str] = None
@@ -115,6 +116,8 @@ class ConsensusConfig:
             raise ValueError(f"unknown parse_mode {self.parse_mode!r}")
         if self.decision_mode not in ("text", "logprob"):
             raise ValueError(f"unknown decision_mode {self.decision_mode!r}")
+        if self.prompt_layout not in ("reference", "persona_last"):
+            raise ValueError(f"unknown prompt_layout {self.prompt_layout!r}")
         names = [m.name for m in self.members]
         if len(set(names)) != len(names):
             raise ValueError("member names must be unique (they are registry keys)")
@@ -150,7 +153,7 @@ class ConsensusConfig:
         }[self.tie_break]
 
     def templates(self) -> "core.PromptTemplates":
-        t = core.PromptTemplates()
+        t = core.PromptTemplates.persona_last() if self.prompt_layout == "persona_last" else core.PromptTemplates()
         for attr, path in (("propose", self.prompt_propose), ("evaluate", self.prompt_evaluate),
                            ("refine", self.prompt_refine)):
             if path:
