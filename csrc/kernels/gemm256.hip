@@ -185,7 +185,69 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const bf16_t* __restrict__
   }
   if (wave < 4) G2_BARRIER();  // balance the stagger barrier
 
-  const int nbase = tn * G2_BN + wn * 64, mbase = c.m0 + wm * 128;
+  const int nbase = tn * G2_BN + wn * 64, mbase = tm * G2_BM + wm * 128;
+  // Epilogue through LDS. Stored straight from the accumulator layout, a wave's store
+  // instruction would touch 16 rows with 32 bytes each; the stores of a tile then cost as much
+  // as ten K-tiles of math. Instead every wave transposes its sub-tile through a private LDS
+  // region (the ring is idle by now) and writes whole rows of it: 16 bytes per lane, 8 (plain)
+  // or 16 (SwiGLU) rows of 128 or 64 contiguous bytes per instruction.
+  if constexpr (EPI != EPI_F32) {
+    if ((ldy & 7) == 0 && (tn + 1) * G2_BN <= N) {   // uniform: the whole block tile is inside Y
+      G2_BARRIER();                                    // every wave is past its last ring read
+      // Staged rows are 128 bytes: a wave's 64 columns, or with SwiGLU the 32 + 32 output
+      // columns of two waves that are neighbours in n (they share a region and split its rows).
+      constexpr int ROWB = 128, CH = 8;
+      char* mine = smem + (EPI == EPI_SWIGLU ? (wm * 2 + (wn >> 1)) : wave) * (128 * ROWB);
+      const int g = lane >> 4, r16 = lane & 15;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int m = j * 16 + r16;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          u32x2 o;
+          int chunk;
+          if constexpr (EPI == EPI_SWIGLU) {
+            if (i & 1) continue;
+            const int nb = nbase + i * 16 + 4 * g;
+            float gt[4], up[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              gt[r] = acc[i][j][r] + (bias ? bf16_to_f32(bias[nb + r]) : 0.f);
+              up[r] = acc[i + 1][j][r] + (bias ? bf16_to_f32(bias[nb + 16 + r]) : 0.f);
+            }
+            o[0] = pack_bf16x2(silu(gt[0]) * up[0], silu(gt[1]) * up[1]);
+            o[1] = pack_bf16x2(silu(gt[2]) * up[2], silu(gt[3]) * up[3]);
+            chunk = (wn & 1) * 4 + (i >> 1) * 2 + (g >> 1);
+          } else {
+            const int nb = nbase + i * 16 + 4 * g;
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r] + (bias ? bf16_to_f32(bias[nb + r]) : 0.f);
+            o[0] = pack_bf16x2(v[0], v[1]);
+            o[1] = pack_bf16x2(v[2], v[3]);
+            chunk = i * 2 + (g >> 1);
+          }
+          // chunk c of row m lives at position c ^ (m mod CH): column accesses spread over banks
+          *reinterpret_cast<u32x2*>(mine + m * ROWB + ((chunk ^ (m & (CH - 1))) << 4) + (g & 1) * 8) = o;
+        }
+      }
+      constexpr int RPI = 64 / CH;                         // rows per store instruction
+      const int c16 = lane & (CH - 1), rsub = lane / CH;
+      const int ncol = (EPI == EPI_SWIGLU ? tn * (G2_BN / 2) + (wn >> 1) * 64 : nbase) + c16 * 8;
+      constexpr int PASSES = EPI == EPI_SWIGLU ? 8 : 16;
+      const int p0 = EPI == EPI_SWIGLU ? (wn & 1) * 8 : 0;
+      if constexpr (EPI == EPI_SWIGLU) G2_BARRIER();       // the partner wave's half rows are in place
+#pragma unroll
+      for (int pp = 0; pp < PASSES; ++pp) {
+        const int p = p0 + pp;
+        const int m = p * RPI + rsub;
+        const u32x4 v = *reinterpret_cast<const u32x4*>(mine + m * ROWB + ((c16 ^ (m & (CH - 1))) << 4));
+        if (mbase + m < M)
+          *reinterpret_cast<u32x4*>(static_cast<bf16_t*>(Y) + static_cast<size_t>(mbase + m) * ldy + ncol) = v;
+      }
+      return;
+    }
+  }
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -198,6 +260,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const bf16_t* __restrict__
       }
     }
 }
+
 
 }  // namespace
 
