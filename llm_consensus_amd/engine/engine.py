@@ -180,7 +180,10 @@ class Engine:
         self.max_group_rows = max_group_rows
         # Decode steps are captured into hipGraphs by default. Steps that contain collectives
         # (tensor / expert parallel members) run eagerly unless asked otherwise: capturing RCCL
-        # calls needs every rank of the group to capture and replay in lock step.
+        # calls needs every rank of the group to capture and replay in lock step, and with
+        # torch 2.10 + ROCm 7.2 a stream capture that contained a torch.distributed all-reduce
+        # ended the process (even at world size 1), so CONSENSUS_GRAPH_COLLECTIVES=1 is an
+        # experiment switch, not a supported mode.
         sharded = model.tp_size > 1 or model.ep_size > 1
         if use_graphs is None:
             use_graphs = not sharded or os.environ.get("CONSENSUS_GRAPH_COLLECTIVES", "0") == "1"

@@ -68,3 +68,4 @@ def test_replica_answer_gather_through_rccl(nccl_world):
     assert answers == [r.answer for r in local] and all(a in "ABCD" for a in answers)
     w = gather_winners(comm, local, "ABCD", dev)
     assert w.is_cuda and w.tolist() == ["ABCD".index(a) for a in answers]
+
