@@ -38,7 +38,24 @@ LC_DEVICE ArgMax argmax_combine(ArgMax a, ArgMax b) {
 template <typename F>
 LC_DEVICE void for_each_strided(const float* __restrict__ row, int V, bool vec, F&& f) {
   if (vec) {
-    for (int i = threadIdx.x * 4; i < V; i += kThreads * 4) {
+    // Four independent 16-byte loads are issued before any of them is consumed: with one
+    // block per row a CU has few waves, and a load-use-load chain leaves it latency-bound at
+    // a fraction of what the L2 can deliver.
+    constexpr int U = 4, STEP = kThreads * 4;
+    int i = threadIdx.x * 4;
+    for (; i + (U - 1) * STEP < V; i += U * STEP) {
+      f32x4 v[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) v[u] = *reinterpret_cast<const f32x4*>(row + i + u * STEP);
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        f(v[u][0], i + u * STEP);
+        f(v[u][1], i + u * STEP + 1);
+        f(v[u][2], i + u * STEP + 2);
+        f(v[u][3], i + u * STEP + 3);
+      }
+    }
+    for (; i < V; i += STEP) {
       const f32x4 v = *reinterpret_cast<const f32x4*>(row + i);
       f(v[0], i);
       f(v[1], i + 1);
