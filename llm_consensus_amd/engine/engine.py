@@ -144,7 +144,9 @@ class _DecodeGraph:
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g, pool=eng.graph_pool):
+        # thread_local: HIP calls made by other threads while this one captures (RCCL's watchdog,
+        # the HTTP front end, another engine's loopback rank) must not invalidate the capture.
+        with torch.cuda.graph(g, pool=eng.graph_pool, capture_error_mode="thread_local"):
             self.out_tokens, self.out_lps, self.out_dec = self.run_body(eng)
         self.graph = g
         if eng.graph_pool is None:
