@@ -1,10 +1,12 @@
 """Checkpoint IO: Hugging Face safetensors -> HBM, and a random-init checkpoint writer.
 
 ``load_model`` memory-maps the ``*.safetensors`` shards of a checkpoint directory
-(``safetensors.safe_open`` executes nothing from the file), slices each tensor to this
-rank's tensor-parallel shard on the host, and hands it to the model, which converts it
-to device layout (fused QKV, interleaved gate/up, MFMA fragment order) on the GPU. Only
-one layer's source tensors are resident on the host at a time.
+(``safetensors.safe_open`` executes nothing from the file). Tensors are handed to the model
+as ``LazyTensor``s: indexing one reads only the requested rows / columns from the mapping, so
+a tensor- or expert-parallel rank touches only its own shard of the file. On a GPU every
+slice goes through a pair of pinned staging buffers (the host copy of slice i+1 overlaps the
+DMA of slice i) and arrives as a device tensor; the model then builds the device layout
+(fused QKV, interleaved gate/up, MFMA fragment order) on the GPU.
 
 The reference has no checkpoints (its model is a remote API,
 /root/reference/src/main.rs:82-86); "checkpoint/resume" for this engine means loading
@@ -22,10 +24,71 @@ from .config import ModelConfig, from_hf_config, get_preset, to_hf_config
 from .transformer import TransformerModel, hf_param_names, hf_param_shape
 
 
+class PinnedStager:
+    """Host -> device copies through two pinned buffers used alternately. A buffer is reused
+    only after the copy that last read it has finished (one event per buffer), so filling
+    buffer B on the CPU overlaps the DMA out of buffer A."""
+
+    def __init__(self, device) -> None:
+        self.device = torch.device(device)
+        self._bufs = [None, None]
+        self._events = [None, None]
+        self._turn = 0
+        self.bytes_moved = 0
+
+    def to_device(self, host: torch.Tensor) -> torch.Tensor:
+        if self.device.type != "cuda":
+            return host
+        host = host.contiguous()
+        n = host.numel() * host.element_size()
+        i = self._turn
+        self._turn ^= 1
+        if self._events[i] is not None:
+            self._events[i].synchronize()
+        if self._bufs[i] is None or self._bufs[i].numel() < n:
+            self._bufs[i] = torch.empty(max(n, 1 << 20), dtype=torch.uint8).pin_memory()
+        stage = self._bufs[i][:n].view(host.dtype).view(host.shape)
+        stage.copy_(host)
+        out = torch.empty(host.shape, dtype=host.dtype, device=self.device)
+        out.copy_(stage, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(self.device))
+        self._events[i] = ev
+        self.bytes_moved += n
+        return out
+
+
+class LazyTensor:
+    """A tensor of a safetensors file that has not been read yet. ``t[a:b]`` / ``t[:, a:b]``
+    read just that part of the mapping; ``t.to(dtype)`` reads all of it. Results are device
+    tensors when a stager for a GPU is attached."""
+
+    def __init__(self, handle, name: str, stager: Optional[PinnedStager] = None) -> None:
+        self._h, self.name, self._stager = handle, name, stager
+        self._slice = handle.get_slice(name)
+
+    @property
+    def shape(self):
+        return tuple(self._slice.get_shape())
+
+    def _out(self, t: torch.Tensor) -> torch.Tensor:
+        return self._stager.to_device(t) if self._stager is not None else t
+
+    def __getitem__(self, idx) -> torch.Tensor:
+        return self._out(self._slice[idx])
+
+    def materialize(self) -> torch.Tensor:
+        return self._out(self._h.get_tensor(self.name))
+
+    def to(self, *args, **kwargs) -> torch.Tensor:
+        return self.materialize().to(*args, **kwargs)
+
+
 class SafetensorsIndex:
     """name -> shard file lookup over a checkpoint directory, with lazy per-tensor reads."""
 
-    def __init__(self, path: str) -> None:
+    def __init__(self, path: str, stager: Optional[PinnedStager] = None) -> None:
+        self.stager = stager
         from safetensors import safe_open
 
         self.dir = Path(path)
@@ -43,7 +106,7 @@ class SafetensorsIndex:
         if not self.where:
             raise FileNotFoundError(f"no safetensors weights under {self.dir}")
 
-    def get(self, name: str) -> torch.Tensor:
+    def get(self, name: str) -> LazyTensor:
         fname = self.where.get(name)
         if fname is None:
             raise KeyError(f"tensor {name!r} not found in {self.dir}")
@@ -51,7 +114,7 @@ class SafetensorsIndex:
         if h is None:
             h = self._open(str(self.dir / fname), framework="pt", device="cpu")
             self._handles[fname] = h
-        return h.get_tensor(name)
+        return LazyTensor(h, name, self.stager)
 
     def __contains__(self, name: str) -> bool:
         return name in self.where
@@ -60,8 +123,8 @@ class SafetensorsIndex:
 def load_model(path: str, device, tp_rank: int = 0, tp_size: int = 1, comm=None,
                cfg: Optional[ModelConfig] = None, ep_size: int = 1, ep_mode: str = "allreduce") -> TransformerModel:
     cfg = cfg or from_hf_config(path)
-    index = SafetensorsIndex(path)
     model = TransformerModel(cfg, device, tp_rank, tp_size, comm, ep_size, ep_mode)
+    index = SafetensorsIndex(path, PinnedStager(model.device))
     model.set_weights_from_hf(index.get)
     return model
 
