@@ -76,8 +76,37 @@ def stream() -> int:
     return torch.cuda.current_stream().cuda_stream
 
 
+# While a list is installed here, every launch is also appended to it as (function, args with
+# the stream): the engine records the launches of one decode step whose buffers are all static
+# and replays them later without going through the ops layer again (see replay()).
+_recording: Optional[list] = None
+
+
+def start_recording() -> list:
+    global _recording
+    _recording = []
+    return _recording
+
+
+def stop_recording() -> None:
+    global _recording
+    _recording = None
+
+
 def call(name: str, *args) -> None:
-    rc = getattr(lib(), name)(*args, stream())
+    fn = getattr(lib(), name)
+    st = stream()
+    rc = fn(*args, st)
     if rc != 0:
         what = "invalid arguments for this kernel" if rc < 0 else f"HIP error {rc}"
         raise KernelLaunchError(f"{name} failed: {what}")
+    if _recording is not None:
+        _recording.append((fn, args + (st,), name))
+
+
+def replay(cmds: list) -> None:
+    """Re-issues recorded launches: one ctypes call each, no allocation, no shape logic."""
+    for fn, args, name in cmds:
+        rc = fn(*args)
+        if rc != 0:
+            raise KernelLaunchError(f"{name} failed on replay: {rc}")

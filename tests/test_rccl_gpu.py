@@ -69,3 +69,31 @@ def test_replica_answer_gather_through_rccl(nccl_world):
     w = gather_winners(comm, local, "ABCD", dev)
     assert w.is_cuda and w.tolist() == ["ABCD".index(a) for a in answers]
 
+
+
+def test_piecewise_decode_graphs_with_rccl_between_them(nccl_world, monkeypatch):
+    """One rank of a two-way tensor-parallel model whose collectives are real RCCL calls
+    (world size 1, so they are identities on half-width tensors): the graphs cut at the
+    collectives must replay correctly with RCCL work enqueued between them."""
+    from llm_consensus_amd._native import core
+    from llm_consensus_amd.engine.engine import Engine
+    from llm_consensus_amd.models.config import get_preset
+    from llm_consensus_amd.models.transformer import TransformerModel
+    from llm_consensus_amd.parallel.comm import TorchDistComm
+
+    dist, dev = nccl_world
+    cfg = get_preset("tiny-llama")
+
+    def run(piecewise):
+        monkeypatch.setenv("CONSENSUS_PIECEWISE", piecewise or "0")
+        m = TransformerModel.random_init(cfg, dev, seed=5, std=0.05, tp_rank=0, tp_size=2, comm=TorchDistComm(dist, dev))
+        eng = Engine(m, num_kv_blocks=64, block_size=16)
+        assert eng.piecewise == piecewise
+        p = core.SamplingParams()
+        p.temperature, p.max_new_tokens, p.ignore_eos = 0.0, 6, True
+        rids = [eng.submit(list(range(2, 30 + 3 * i)), params=p) for i in range(3)]
+        eng.run_until_done()
+        return [eng.pop_result(r).token_ids[0] for r in rids]
+
+    want = run("")
+    assert run("graphs") == want and run("lists") == want
