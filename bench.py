@@ -221,9 +221,15 @@ def main() -> None:
         # Two prompt layouts: the reference's (domain named a third of the way into the evaluate
         # prompt) and the same instructions with the persona text moved to the end, which lets
         # the four evaluate prompts of a round share most of their prefill.
-        for key, templates in (("reference_protocol", core.PromptTemplates()),
-                               ("reference_protocol_persona_last", core.PromptTemplates.persona_last())):
-            panel = [Member(p, be_p, templates, gp_p, decision_mode="logprob") for p in personas[:4]]
+        # Random-init weights give all four personas the same verdict (always Good here), so the
+        # loop ends after one round; the third run injects seeded dissent (a Good verdict becomes
+        # NeedsRefinement with probability 0.25) to load the refinement path as well.
+        for key, templates, dissent in (
+                ("reference_protocol", core.PromptTemplates(), 0.0),
+                ("reference_protocol_persona_last", core.PromptTemplates.persona_last(), 0.0),
+                ("reference_protocol_persona_last_dissent25", core.PromptTemplates.persona_last(), 0.25)):
+            panel = [Member(p, be_p, templates, gp_p, decision_mode="logprob", dissent_rate=dissent,
+                            dissent_seed=1000 * rank + i) for i, p in enumerate(personas[:4])]
             sess = core.SessionConfig()
             sess.max_rounds, sess.seed = 5, 4242 + rank
             coord = Coordinator(panel, sess)
@@ -246,6 +252,7 @@ def main() -> None:
                 "mean_rounds": round(float(np.mean([r.rounds for r in kept])), 2),
                 "mean_member_calls": round(float(np.mean([r.member_calls for r in kept])), 2),
                 "forced_fraction": round(float(np.mean([r.forced for r in kept])), 3),
+                "injected_dissent_rate": dissent,
                 "prefix_cache_hit_rate": round(float(hit), 3),
             }
     if rank == 0:

@@ -11,6 +11,7 @@ decision instead of free text (``decision_mode="logprob"``).
 from __future__ import annotations
 
 from dataclasses import dataclass
+import numpy as np
 from typing import List, Optional, Tuple
 
 from .._native import core
@@ -41,6 +42,8 @@ class Member:
         decision_mode: str = "text",
         role: str = "member",
         weight: float = 1.0,
+        dissent_rate: float = 0.0,
+        dissent_seed: int = 0,
     ) -> None:
         self.persona = persona
         self.backend = backend
@@ -50,6 +53,12 @@ class Member:
         self.decision_mode = decision_mode
         self.role = role
         self.weight = weight
+        # Fault injection for tests and synthetic benchmarks: a Good verdict is turned into
+        # NeedsRefinement with this probability (seeded, per evaluation), so the refinement
+        # loop runs even when the model behind the member never objects -- random-init weights
+        # give every persona the same two-way decision.
+        self.dissent_rate = dissent_rate
+        self._dissent_rng = np.random.default_rng(dissent_seed) if dissent_rate > 0 else None
 
     @property
     def name(self) -> str:
@@ -81,6 +90,13 @@ class Member:
     def finish_evaluate(self, h: Handle) -> Evaluation:
         """Turns a completed evaluate handle into a verdict. Raises BackendError if the
         request failed; the caller maps that to abstain / NeedsRefinement."""
+        ev = self._finish_evaluate(h)
+        if self._dissent_rng is not None and ev.verdict == core.Verdict.Good and \
+                self._dissent_rng.random() < self.dissent_rate:
+            return Evaluation(core.Verdict.NeedsRefinement, "injected dissent", ev.well_formed, ev.logprobs)
+        return ev
+
+    def _finish_evaluate(self, h: Handle) -> Evaluation:
         res = h.result()
         if h.tag == "logprob":
             good, needs = float(res[0]), float(res[1])

@@ -193,3 +193,19 @@ def test_deadline_returns_current_answer():
 def test_no_members_is_an_error():
     with pytest.raises(RuntimeError):
         Coordinator([]).ask("q")
+
+
+def test_injected_dissent_drives_the_refinement_loop():
+    """Members that would always say Good (as random-init models do under the log-prob decision)
+    still exercise refinement when seeded dissent is injected; the protocol's bounds hold."""
+    from llm_consensus_amd.consensus.backend import ScriptedBackend
+    from llm_consensus_amd.consensus.members import Member
+    from llm_consensus_amd.consensus.protocol import Coordinator
+
+    be = ScriptedBackend(default_verdict="Good")
+    members = [Member(p, be, dissent_rate=0.5, dissent_seed=i) for i, p in enumerate(core.default_personas())]
+    res = Coordinator(members).ask_many([f"q{i}" for i in range(12)])
+    assert all(r.answer for r in res) and all(1 <= r.rounds <= 5 for r in res)
+    assert any(r.rounds > 1 for r in res) and all(r.member_calls <= 1 + 5 * 4 + 5 for r in res)
+    calm = Coordinator([Member(p, be) for p in core.default_personas()]).ask_many(["q"])
+    assert calm[0].rounds == 1 and calm[0].unanimous
