@@ -54,11 +54,16 @@ class Ensemble:
         t0 = time.perf_counter()
         with span("ask_many", "ensemble", questions=len(qs), strategy=self.config.strategy):
             results = self.strategy.ask_many(qs)
-        dt = time.perf_counter() - t0
+        self.metrics.inc("batches")
+        self.metrics.inc("seconds", time.perf_counter() - t0)
+        self.record(results)
+        return results
+
+    def record(self, results) -> None:
+        """Ensemble-level counters for finished questions (also used by drivers that do not go
+        through ask_many, such as the server's continuous loop)."""
         m = self.metrics
         m.inc("answers", len(results))
-        m.inc("batches")
-        m.inc("seconds", dt)
         for r in results:
             m.observe("latency_ms", r.latency_s * 1e3)
             m.observe("rounds", r.rounds)
@@ -68,7 +73,6 @@ class Ensemble:
             m.inc("forced", 1 if getattr(r, "forced", False) else 0)
             instant("session.done", "ensemble", rounds=r.rounds, calls=r.member_calls, unanimous=r.unanimous,
                     latency_ms=round(r.latency_s * 1e3, 2))
-        return results
 
     def stats(self) -> Dict[str, Dict[str, float]]:
         """Per-model engine statistics plus a ``consensus`` section (answers/s, latency

@@ -99,6 +99,16 @@ class Backend:
         """Drive the backend until every submitted handle is done."""
         raise NotImplementedError
 
+    # Backends that can make progress in small increments set this; a driver may then keep
+    # admitting new work between increments instead of running whole batches to completion.
+    incremental = False
+
+    def poll(self) -> bool:
+        """Makes some progress on the submitted requests and completes the handles of those
+        that finished. Returns True while requests remain. The default runs everything."""
+        self.run()
+        return False
+
     def run_local(self) -> None:
         """Compute phase of run(): everything that needs no other backend's ranks."""
         self.run()

@@ -90,9 +90,17 @@ class Coordinator:
     def ask(self, question: str) -> ConsensusResult:
         return self.ask_many([question])[0]
 
-    def ask_many(self, questions: Sequence[str]) -> List[ConsensusResult]:
+    def ask_many(self, questions: Sequence[str], continuous: bool = False) -> List[ConsensusResult]:
+        """Answers all questions. By default the sessions advance in waves (every session's
+        pending calls, then all backends to completion); ``continuous`` lets each session move
+        on as soon as its own calls are done (see SessionPool)."""
         if not self.members:
             raise RuntimeError("no members registered")  # the reference panics in choose() (main.rs:229)
+        if continuous:
+            pool = SessionPool(self)
+            tickets = [pool.submit(q) for q in questions]
+            done = dict(pool.drain())
+            return [done[t] for t in tickets]
         names = [m.name for m in self.members]
         live: List[_Live] = []
         for q in questions:
@@ -106,43 +114,50 @@ class Coordinator:
         pending = list(live)
         wave = 0
         while pending:
-            # ---- submit ----
             for L in pending:
-                s, a = L.session, L.action
-                L.handles = []
-                if a.kind == K.Propose:
-                    L.handles = [self.members[a.member].submit_propose(s.question)]
-                elif a.kind == K.Evaluate:
-                    log.debug("Asking actors to evaluate answer.")
-                    L.handles = [m.submit_evaluate(s.question, s.answer()) for m in self.members]
-                elif a.kind == K.Refine:
-                    log.debug("Asking %s to refine the answer.", self.members[a.member].name)
-                    L.handles = [self.members[a.member].submit_refine(s.question, s.answer(), s.refiner_context())]
-            # ---- run ----
+                self._submit(L)
             wave += 1
             with span(f"wave{wave}", "protocol", sessions=len(pending),
                       calls=sum(len(L.handles) for L in pending)):
                 run_backends(backends)
-            # ---- collect ----
             nxt: List[_Live] = []
             for L in pending:
-                try:
-                    L.action = self._advance(L)
-                except BackendError as e:
-                    # A failed propose/refine leaves nothing to vote on: finish with what we have.
-                    log.error("member call failed: %s", e)
-                    L.failed = str(e)
-                    L.action = L.session.abort_with_current_answer()
-                if L.action.kind != K.Done and self.deadline_s is not None and \
-                        time.perf_counter() - L.t0 > self.deadline_s and L.session.has_answer:
-                    log.debug("Deadline exceeded; returning the current answer.")
-                    L.action = L.session.abort_with_current_answer()
-                if L.action.kind == K.Done:
-                    results[L.index] = self._finish(L)
+                res = self._collect(L)
+                if res is not None:
+                    results[L.index] = res
                 else:
                     nxt.append(L)
             pending = nxt
         return results  # type: ignore[return-value]
+
+    def _submit(self, L: _Live) -> None:
+        """Issues the member calls of the session's pending action (non-blocking)."""
+        s, a = L.session, L.action
+        L.handles = []
+        if a.kind == K.Propose:
+            L.handles = [self.members[a.member].submit_propose(s.question)]
+        elif a.kind == K.Evaluate:
+            log.debug("Asking actors to evaluate answer.")
+            L.handles = [m.submit_evaluate(s.question, s.answer()) for m in self.members]
+        elif a.kind == K.Refine:
+            log.debug("Asking %s to refine the answer.", self.members[a.member].name)
+            L.handles = [self.members[a.member].submit_refine(s.question, s.answer(), s.refiner_context())]
+
+    def _collect(self, L: _Live) -> Optional[ConsensusResult]:
+        """Feeds the completed member calls to the session. Returns the result when the
+        session is finished, None when it has a next action to submit."""
+        try:
+            L.action = self._advance(L)
+        except BackendError as e:
+            # A failed propose/refine leaves nothing to vote on: finish with what we have.
+            log.error("member call failed: %s", e)
+            L.failed = str(e)
+            L.action = L.session.abort_with_current_answer()
+        if L.action.kind != K.Done and self.deadline_s is not None and \
+                time.perf_counter() - L.t0 > self.deadline_s and L.session.has_answer:
+            log.debug("Deadline exceeded; returning the current answer.")
+            L.action = L.session.abort_with_current_answer()
+        return self._finish(L) if L.action.kind == K.Done else None
 
     # ------------------------------------------------------------------
     def _advance(self, L: _Live):
@@ -206,3 +221,71 @@ class Coordinator:
             with open(self.transcript_path, "a") as f:
                 f.write(res.to_json() + "\n")
         return res
+
+
+class SessionPool:
+    """The protocol driver without waves: sessions are admitted at any time and each one moves
+    to its next action as soon as ITS member calls have completed, while the backends are
+    advanced one engine step at a time in between. A question that arrives while others are
+    being answered joins the running batch at the next step instead of waiting for it to
+    drain (the reference serves one question at a time and polls it every 500 ms,
+    /root/reference/src/main.rs:428-471). Needs backends that live in this process; ranks of a
+    distributed ensemble must stay in lock step and use the wave driver."""
+
+    def __init__(self, coordinator: Coordinator) -> None:
+        self.c = coordinator
+        self.backends = distinct_backends(coordinator.members)
+        self.live: Dict[int, _Live] = {}
+        self._next = 0
+
+    @property
+    def active(self) -> int:
+        return len(self.live)
+
+    def submit(self, question: str) -> int:
+        """Admits a question; returns its ticket."""
+        c = self.c
+        if not c.members:
+            raise RuntimeError("no members registered")
+        s = core.ConsensusSession([m.name for m in c.members], c.session_config, c._asked)
+        c._asked += 1
+        L = _Live(s, s.ask(question), self._next)
+        self._next += 1
+        c._submit(L)
+        self.live[L.index] = L
+        return L.index
+
+    def pump(self) -> List[tuple]:
+        """One round of progress. Returns [(ticket, ConsensusResult)] of the sessions that
+        finished in it."""
+        finished = []
+        for t, L in list(self.live.items()):
+            if not all(h.done for h in L.handles):
+                continue
+            res = self.c._collect(L)
+            if res is not None:
+                finished.append((t, res))
+                del self.live[t]
+            else:
+                self.c._submit(L)
+        stepping = [(b, e) for b in self.backends if b.incremental for e in b.engines() if e.has_work()]
+        if len(stepping) > 1:
+            # steps of different members' engines overlap on their own streams
+            tokens = [(b, e, e.begin_step()) for b, e in stepping]
+            for b, e, tok in tokens:
+                if tok is not None:
+                    e.end_step(tok)
+            for b in {id(b): b for b, _ in stepping}.values():
+                b.harvest()
+            rest = [b for b in self.backends if not b.incremental]
+        else:
+            rest = self.backends
+        for b in rest:
+            b.poll()
+        return finished
+
+    def drain(self) -> List[tuple]:
+        out = []
+        while self.live:
+            out += self.pump()
+        return out

@@ -65,20 +65,48 @@ class EngineBackend(Backend):
             h.set_error(e)
         return h
 
+    incremental = True
+
     def run(self) -> None:
         try:
             self.engine.run_until_done()
         except Exception as e:
-            for rid, (_, h) in self._pending.items():
-                if not h.done:
-                    h.set_error(BackendError(f"engine failure: {e}"))
-            self._pending.clear()
+            self._fail_all(e)
             raise
+        self._harvest(final=True)
+
+    def poll(self) -> bool:
+        """One engine step, then the handles of whatever finished in it."""
+        try:
+            if self.engine.has_work():
+                self.engine.step()
+        except Exception as e:
+            self._fail_all(e)
+            raise
+        self._harvest(final=not self.engine.has_work())
+        return bool(self._pending)
+
+    def harvest(self) -> bool:
+        """Completes the handles of requests the engine has finished (for drivers that step
+        the engine themselves). Returns True while requests remain."""
+        self._harvest(final=not self.engine.has_work())
+        return bool(self._pending)
+
+    def _fail_all(self, e: Exception) -> None:
+        for rid, (_, h) in self._pending.items():
+            if not h.done:
+                h.set_error(BackendError(f"engine failure: {e}"))
+        self._pending.clear()
+
+    def _harvest(self, final: bool) -> None:
         for rid, (kind, h) in list(self._pending.items()):
             out = self.engine.pop_result(rid)
             if out is None:
-                h.set_error(BackendError("request did not finish"))
+                if final:
+                    h.set_error(BackendError("request did not finish"))
+                    del self._pending[rid]
                 continue
+            del self._pending[rid]
             if kind == "gen":
                 eos = self.tok.eos_id
                 texts = []
@@ -93,7 +121,6 @@ class EngineBackend(Backend):
                 h.set_result(out.scores)
             else:
                 h.set_result(out.embedding)
-        self._pending.clear()
 
     def engines(self) -> list:
         return [self.engine] if self._pending else []

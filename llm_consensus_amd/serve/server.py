@@ -64,8 +64,9 @@ class HTTPError(Exception):
 
 class ConsensusServer:
     def __init__(self, ensemble, host: str = "127.0.0.1", port: int = 8000, max_batch: int = 64,
-                 batch_window_ms: float = 5.0, request_timeout_s: float = 600.0) -> None:
+                 batch_window_ms: float = 5.0, request_timeout_s: float = 600.0, continuous: bool = True) -> None:
         self.ensemble = ensemble
+        self.continuous = continuous
         self.max_batch, self.window = max_batch, batch_window_ms / 1e3
         self.request_timeout_s = request_timeout_s
         self.jobs: "queue.Queue[_Job]" = queue.Queue()
@@ -135,7 +136,84 @@ class ConsensusServer:
                 break
         return batch
 
+    def _continuous_ok(self) -> bool:
+        """The reference protocol over backends that live in this process can be driven
+        without batch boundaries (SessionPool); everything else runs batch by batch."""
+        from ..consensus.protocol import Coordinator
+
+        strat = getattr(self.ensemble, "strategy", None)
+        return (self.continuous and type(strat) is Coordinator
+                and all(getattr(b, "incremental", False) for b in self.ensemble.backends.values()))
+
+    def _drive_continuous(self) -> None:
+        """New questions join the sessions in flight at the next engine step; every request is
+        answered as soon as its own session (or generation) is done."""
+        from ..consensus.protocol import SessionPool
+
+        pool = SessionPool(self.ensemble.strategy)
+        tickets: Dict[int, _Job] = {}
+        direct: List[tuple] = []
+        while not self._stop.is_set():
+            idle = not tickets and not direct
+            try:
+                new = [self.jobs.get(timeout=0.05)] if idle else []
+            except queue.Empty:
+                continue
+            while len(tickets) + len(direct) + len(new) < 4 * self.max_batch:
+                try:
+                    new.append(self.jobs.get_nowait())
+                except queue.Empty:
+                    break
+            if new:
+                with self._lock:
+                    self.counters["batches_total"] += 1
+                    self.counters["batched_requests_total"] += len(new)
+            for j in new:
+                try:
+                    if j.kind == "consensus":
+                        tickets[pool.submit(j.text)] = j
+                    else:
+                        be = self.ensemble.backends[j.model]
+                        direct.append((be.submit_embed(j.text) if j.kind == "embed"
+                                       else be.submit_generate(j.text, j.params), j))
+                except Exception as e:  # noqa: BLE001
+                    j.error = f"{type(e).__name__}: {e}"
+                    j.done.set()
+            try:
+                finished = pool.pump()
+                if not pool.active:          # nothing for the pool to step: direct requests only
+                    for be in {id(b): b for b in self.ensemble.backends.values()}.values():
+                        if be.engines():
+                            be.poll()
+            except Exception as e:  # noqa: BLE001  never let the driver die with waiters parked on it
+                log.error("engine step failed: %s", e)
+                for j in list(tickets.values()) + [j for _, j in direct]:
+                    j.error = f"{type(e).__name__}: {e}"
+                    j.done.set()
+                tickets.clear()
+                direct.clear()
+                pool = SessionPool(self.ensemble.strategy)
+                continue
+            for t, res in finished:
+                j = tickets.pop(t)
+                j.result = res
+                self.ensemble.record([res])
+                j.done.set()
+            still = []
+            for h, j in direct:
+                if not h.done:
+                    still.append((h, j))
+                    continue
+                try:
+                    j.result = h.result()
+                except BackendError as e:
+                    j.error = str(e)
+                j.done.set()
+            direct = still
+
     def _drive(self) -> None:
+        if self._continuous_ok():
+            return self._drive_continuous()
         while not self._stop.is_set():
             batch = self._collect()
             if not batch:
@@ -390,6 +468,8 @@ def main(argv: Optional[list] = None) -> int:
     ap.add_argument("--batch-window-ms", type=float, default=5.0)
     ap.add_argument("--distributed", action="store_true",
                     help="one process per GPU under torch.distributed.run; rank 0 serves HTTP")
+    ap.add_argument("--batched", action="store_true",
+                    help="answer in closed batches even where the continuous driver applies")
     args = ap.parse_args(argv)
     cfg = load_config(args.config)
     if args.distributed:
@@ -404,7 +484,8 @@ def main(argv: Optional[list] = None) -> int:
     else:
         ens = build_ensemble(cfg)
     try:
-        ConsensusServer(ens, args.host, args.port, args.max_batch, args.batch_window_ms).serve_forever()
+        ConsensusServer(ens, args.host, args.port, args.max_batch, args.batch_window_ms,
+                        continuous=not args.batched).serve_forever()
     finally:
         if args.distributed:
             ens.close()

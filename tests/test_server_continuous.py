@@ -1,0 +1,62 @@
+"""The HTTP server's continuous driver: reference-protocol sessions and direct completions
+admitted at different times share the engine, each answered as soon as it is done."""
+import json
+import threading
+import time
+import urllib.request
+
+import pytest
+
+from llm_consensus_amd.app import build_ensemble
+from llm_consensus_amd.config import config_from_dict
+from llm_consensus_amd.serve.server import ConsensusServer
+
+
+def _post(port, path, body, timeout=300):
+    req = urllib.request.Request(f"http://127.0.0.1:{port}{path}", json.dumps(body).encode(),
+                                 {"Content-Type": "application/json"})
+    with urllib.request.urlopen(req, timeout=timeout) as r:
+        return r.status, json.loads(r.read())
+
+
+@pytest.fixture(scope="module")
+def server():
+    cfg = config_from_dict({"strategy": "reference_protocol", "decision_mode": "logprob", "seed": 3,
+                            "sampling": {"temperature": 0.0, "max_new_tokens": 4},
+                            "models": {"default": {"preset": "tiny-llama", "seed": 1}}})
+    ens = build_ensemble(cfg)
+    srv = ConsensusServer(ens, port=0, max_batch=8).start()
+    assert srv._continuous_ok()
+    yield srv, ens
+    srv.shutdown()
+
+
+def test_staggered_questions_and_a_direct_completion_are_all_answered(server):
+    srv, ens = server
+    out = {}
+
+    def ask(i, delay):
+        time.sleep(delay)
+        out[i] = _post(srv.port, "/v1/chat/completions", {"messages": [{"role": "user", "content": f"question {i}"}]})
+
+    def complete():
+        time.sleep(0.05)
+        out["direct"] = _post(srv.port, "/v1/completions", {"model": "default", "prompt": "hello", "max_tokens": 3})
+
+    ts = [threading.Thread(target=ask, args=(i, 0.03 * i)) for i in range(5)] + [threading.Thread(target=complete)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    for i in range(5):
+        st, body = out[i]
+        assert st == 200 and body["consensus"]["strategy"] == "reference_protocol"
+        assert 1 <= body["consensus"]["rounds"] <= 5 and isinstance(body["choices"][0]["message"]["content"], str)
+    assert out["direct"][0] == 200 and len(out["direct"][1]["choices"]) == 1
+    st = ens.stats()["consensus"]
+    assert st["answers"] == 5 and st["member_calls"] >= 25
+
+
+def test_batched_mode_is_still_available(server):
+    srv, ens = server
+    batched = ConsensusServer(ens, port=0, continuous=False)
+    assert not batched._continuous_ok()
+    batched.httpd.server_close()
