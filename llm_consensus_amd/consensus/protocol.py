@@ -23,7 +23,7 @@ from typing import Dict, List, Optional, Sequence
 
 from .._native import core
 from ..utils.log import get_logger
-from ..utils.trace import span
+from ..utils.trace import instant, span
 from .backend import BackendError, Handle, run_backends
 from .members import Member, distinct_backends
 
@@ -142,6 +142,10 @@ class Coordinator:
         elif a.kind == K.Refine:
             log.debug("Asking %s to refine the answer.", self.members[a.member].name)
             L.handles = [self.members[a.member].submit_refine(s.question, s.answer(), s.refiner_context())]
+        # per-session timeline: one event per protocol transition (the wave spans only exist in
+        # the wave driver)
+        instant(f"session.{a.kind.name.lower()}", "protocol", session=L.index, round=s.evaluation_count,
+                calls=len(L.handles), member=self.members[a.member].name if a.kind != K.Evaluate else "*")
 
     def _collect(self, L: _Live) -> Optional[ConsensusResult]:
         """Feeds the completed member calls to the session. Returns the result when the
