@@ -503,6 +503,79 @@ __global__ __launch_bounds__(64) void attn_prefix_kernel(const bf16_t* __restric
   finish_and_store<DH>(st, nullptr, valid ? part_o + slot * DH : nullptr, valid ? part_lse + slot : nullptr, lane);
 }
 
+// Multi-wave form of the shared-prefix pass: the NW waves of a workgroup take consecutive
+// pieces of the split's key range and their partial results are merged by log-sum-exp in LDS,
+// so a group's prefix costs one partial slot per row in HBM instead of one per piece (with five
+// pieces of a 512-key prompt the slots, written here and read again by the merge kernel, were
+// more traffic than the prefix keys themselves).
+template <int DH, int NW>
+__global__ __launch_bounds__(64 * NW) void attn_prefix_mw_kernel(
+    const bf16_t* __restrict__ Q, int q_stride, const bf16_t* __restrict__ Kc, const bf16_t* __restrict__ Vt,
+    const int32_t* __restrict__ block_tables, int max_blocks, const int32_t* __restrict__ group_first,
+    const int32_t* __restrict__ group_count, const int32_t* __restrict__ group_shared_blocks, int nsplit,
+    float* __restrict__ part_o, float* __restrict__ part_lse, int np_total, int slot0, int Hq, int Hkv, int lbs,
+    float scale2) {
+  extern __shared__ __attribute__((aligned(16))) char pm_smem[];
+  float(*sm_o)[32][DH] = reinterpret_cast<float(*)[32][DH]>(pm_smem);
+  float(*sm_m)[32] = reinterpret_cast<float(*)[32]>(pm_smem + sizeof(float) * NW * 32 * DH);
+  float(*sm_l)[32] = sm_m + NW;
+  const int grp = blockIdx.z / nsplit, split = blockIdx.z % nsplit;
+  const int kvh = blockIdx.y;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int G = Hq / Hkv;
+  const int first = group_first[grp], count = group_count[grp];
+  const int plen = group_shared_blocks[grp] << lbs;
+  if (blockIdx.x * 32 >= count * G) return;     // block-uniform: an empty group slot
+  const int q = lane & 31, hh = lane >> 5;
+  const int row = blockIdx.x * 32 + q;
+  const bool valid = row < count * G;
+  const int b = first + row / G;
+  const int head = kvh * G + row % G;
+  const int per = ((plen + 31) / 32 + nsplit * NW - 1) / (nsplit * NW);   // 32-key tiles per wave
+  const int part = split * NW + wave;
+  const int lo = min(plen, part * per * 32);
+  const int hi = min(plen, (part + 1) * per * 32);
+
+  bf16x8 qf[DH / 16];
+  load_q<DH>(qf, valid ? Q + static_cast<size_t>(b) * q_stride + head * DH : nullptr, lane);
+  TileCtx c{Kc, Vt, block_tables + static_cast<size_t>(first) * max_blocks, Hkv, kvh, lbs, 1 << lbs, scale2};
+  AttnState<DH> st;
+  init_state<DH>(st);
+  if (lo < hi) attend_range<DH>(st, qf, c, lo, hi, valid ? lo : 0, valid ? hi : 0, lane);
+
+  const float l_all = st.l + __shfl_xor(st.l, 32, 64);
+  if (hh == 0) {
+    sm_m[wave][q] = st.m;
+    sm_l[wave][q] = l_all;
+  }
+#pragma unroll
+  for (int blk = 0; blk < DH / 32; ++blk)
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4)
+      *reinterpret_cast<f32x4*>(&sm_o[wave][q][blk * 32 + 8 * g4 + 4 * hh]) =
+          f32x4{st.o[blk][4 * g4 + 0], st.o[blk][4 * g4 + 1], st.o[blk][4 * g4 + 2], st.o[blk][4 * g4 + 3]};
+  __syncthreads();
+  for (int e = threadIdx.x; e < 32 * DH; e += 64 * NW) {
+    const int qq = e / DH, d = e % DH;
+    const int r2 = blockIdx.x * 32 + qq;
+    if (r2 >= count * G) continue;
+    float mx = kNegBig;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) mx = fmaxf(mx, sm_m[w][qq]);
+    float num = 0.f, den = 0.f;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+      const float sc = exp2f(sm_m[w][qq] - mx);
+      num += sc * sm_o[w][qq][d];
+      den += sc * sm_l[w][qq];
+    }
+    const size_t slot = (static_cast<size_t>(first + r2 / G) * Hq + kvh * G + r2 % G) * np_total + slot0 + split;
+    part_o[slot * DH + d] = den > 0.f ? num / den : 0.f;
+    if (d == 0) part_lse[slot] = den > 0.f ? mx + log2f(den) : kNegBig;
+  }
+}
+
 // ------------------------------------------------------------------ merge
 // out[b, head, :] = sum_p w_p * part_o[b, head, p, :],  w_p = 2^(lse_p - max) / sum.
 // One wave per (b, head); lanes cover Dh.
@@ -609,11 +682,11 @@ LC_EXPORT int lc_attn_prefix(const void* Q, int q_stride, const void* Kc, const 
                              const void* block_tables, int max_blocks, const void* group_first,
                              const void* group_count, const void* group_shared_blocks, int n_groups,
                              int max_group_rows, int nsplit, void* part_o, void* part_lse, int np_total,
-                             int slot0, int Hq, int Hkv, int Dh, int block_size, float scale,
+                             int slot0, int Hq, int Hkv, int Dh, int block_size, float scale, int waves,
                              hipStream_t stream) {
   if (n_groups <= 0 || max_group_rows <= 0) return 0;
   if (Hq % Hkv || (Dh != 64 && Dh != 128) || block_size % 8 || (block_size & (block_size - 1)) ||
-      nsplit < 1 || slot0 + nsplit > np_total)
+      nsplit < 1 || slot0 + nsplit > np_total || (waves != 1 && waves != 4))
     return -1;
   const int G = Hq / Hkv;
   const dim3 grid((max_group_rows * G + 31) / 32, Hkv, n_groups * nsplit), block(64);
@@ -624,8 +697,21 @@ LC_EXPORT int lc_attn_prefix(const void* Q, int q_stride, const void* Kc, const 
       static_cast<const int32_t*>(block_tables), max_blocks, static_cast<const int32_t*>(group_first),   \
       static_cast<const int32_t*>(group_count), static_cast<const int32_t*>(group_shared_blocks), nsplit, \
       static_cast<float*>(part_o), static_cast<float*>(part_lse), np_total, slot0, Hq, Hkv, lbs, scale2
-  if (Dh == 128) attn_prefix_kernel<128><<<grid, block, 0, stream>>>(LC_ARGS);
-  else attn_prefix_kernel<64><<<grid, block, 0, stream>>>(LC_ARGS);
+  if (waves == 4) {
+    const size_t lds = sizeof(float) * 4 * 32 * (Dh + 2);
+    static bool attr_set = false;
+    if (!attr_set) {
+      hipFuncSetAttribute(reinterpret_cast<const void*>(attn_prefix_mw_kernel<128, 4>),
+                          hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(sizeof(float) * 4 * 32 * 130));
+      attr_set = true;
+    }
+    if (Dh == 128) attn_prefix_mw_kernel<128, 4><<<grid, dim3(256), lds, stream>>>(LC_ARGS);
+    else attn_prefix_mw_kernel<64, 4><<<grid, dim3(256), lds, stream>>>(LC_ARGS);
+  } else if (Dh == 128) {
+    attn_prefix_kernel<128><<<grid, block, 0, stream>>>(LC_ARGS);
+  } else {
+    attn_prefix_kernel<64><<<grid, block, 0, stream>>>(LC_ARGS);
+  }
 #undef LC_ARGS
   LC_RETURN_LAST_ERROR();
 }

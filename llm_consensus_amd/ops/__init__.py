@@ -356,6 +356,9 @@ def attn_prefill(qkv, k_cache, vt_cache, block_tables, cu_q, ctx_lens, max_q_len
     return out
 
 
+ATTN_PREFIX_WAVES = 4   # 1 = one wave per prefix piece and one partial slot per piece
+
+
 def choose_kv_splits(B: int, Hkv: int, max_ctx: int) -> int:
     """KV splits per (sequence, kv head): about 1024 waves in total (4 per CU) without slicing
     below 128 keys. Measured with an HBM-resident cache (benchmarks/attn_decode_bench.py): fewer
@@ -393,6 +396,9 @@ def attn_decode(qkv, k_cache, vt_cache, block_tables, ctx_lens, Hq, Hkv, Dh, sca
                block_tables.data_ptr(), block_tables.shape[1], ctx_lens.data_ptr(), None, out.data_ptr(), None, None,
                1, 1, B, Hq, Hkv, Dh, k_cache.shape[2], float(scale), int(window), waves)
         return out
+    # The prefix pass merges four pieces of its key range on chip the same way.
+    pwaves = 4 if (use_prefix and prefix_splits >= 4 and ATTN_PREFIX_WAVES >= 4) else 1
+    prefix_splits = max(1, prefix_splits // pwaves)
     np_total = nsplit + (prefix_splits if use_prefix else 0)
     part_o = torch.empty(B, Hq, np_total, Dh, dtype=torch.float32, device=qkv.device)
     part_lse = torch.empty(B, Hq, np_total, dtype=torch.float32, device=qkv.device)
@@ -405,7 +411,7 @@ def attn_decode(qkv, k_cache, vt_cache, block_tables, ctx_lens, Hq, Hkv, Dh, sca
         h.call("lc_attn_prefix", qkv.data_ptr(), qkv.stride(0), k_cache.data_ptr(), vt_cache.data_ptr(),
                block_tables.data_ptr(), block_tables.shape[1], gf.data_ptr(), gc.data_ptr(), gs.data_ptr(),
                gf.numel(), int(max_group_rows), int(prefix_splits), part_o.data_ptr(), part_lse.data_ptr(), np_total,
-               nsplit, Hq, Hkv, Dh, k_cache.shape[2], float(scale))
+               nsplit, Hq, Hkv, Dh, k_cache.shape[2], float(scale), pwaves)
     h.call("lc_attn_merge", part_o.data_ptr(), part_lse.data_ptr(), out.data_ptr(), np_total, B * Hq, Dh)
     return out
 

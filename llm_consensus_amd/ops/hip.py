@@ -33,7 +33,7 @@ _SIGNATURES = {
     "lc_rope_kv_write": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _I, _P, _P],
     "lc_attn_prefill": [_P, _I, _P, _P, _P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _F, _I, _P],
     "lc_attn_decode": [_P, _I, _P, _P, _P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _F, _I, _I, _P],
-    "lc_attn_prefix": [_P, _I, _P, _P, _P, _I, _P, _P, _P, _I, _I, _I, _P, _P, _I, _I, _I, _I, _I, _I, _F, _P],
+    "lc_attn_prefix": [_P, _I, _P, _P, _P, _I, _P, _P, _P, _I, _I, _I, _P, _P, _I, _I, _I, _I, _I, _I, _F, _I, _P],
     "lc_attn_merge": [_P, _P, _P, _I, _I, _I, _P],
     "lc_fill_f32": [_P, _F, _L, _P],
     "lc_sample": [_P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P],

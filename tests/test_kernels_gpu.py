@@ -301,7 +301,7 @@ def test_shared_prefix_decode_equals_unshared(Hq, Hkv, Dh, BS, K):
     groups = (torch.tensor([0], dtype=torch.int32, device=DEV), torch.tensor([K], dtype=torch.int32, device=DEV),
               torch.tensor([3], dtype=torch.int32, device=DEV))
     kv_begin = torch.full((K,), 3 * BS, dtype=torch.int32, device=DEV)
-    for nsplit, psplit in ((1, 1), (2, 3)):
+    for nsplit, psplit in ((1, 1), (2, 3), (1, 4), (2, 8), (1, 5)):   # >= 4: the multi-wave prefix pass
         got = ops.attn_decode(rows.to(DEV), kc.to(DEV), vc.to(DEV), tables.to(DEV), ctx.to(DEV), Hq, Hkv, Dh, scale,
                               nsplit=nsplit, groups=groups, kv_begin=kv_begin, max_group_rows=K, prefix_splits=psplit)
         assert rel_err(got, want) < 1e-2
