@@ -37,8 +37,8 @@ def run():
     for _ in range(3):
         ops.linear(x8k, w_gu)          # gemm256 (SwiGLU epilogue)
         ops.linear(x8k, w_o)           # gemm256
-        ops.linear(x256, w_gu)         # gemm_m256
-        ops.linear(x64, w_gu)          # wsgemm split-K + reduce
+        ops.linear(x256, w_gu)         # gemm_panel, 256-row panel
+        ops.linear(x64, w_gu)          # gemm_panel, 64-row panel (SwiGLU epilogue)
         ops.linear(x64, w_o, defer_reduce=True)
         ops.linear(a64, w_dn, defer_reduce=True)
     # ---- attention at the benchmark's shapes (Llama-3-8B: 32 q heads, 8 kv heads, Dh 128)
