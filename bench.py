@@ -183,9 +183,14 @@ def main() -> None:
     }
     if not a.skip_self_consistency:
         steps_b = a.sc_steps or a.steps
+        st_before = members[0].backend.stats()
         el_b, n_b, lat_b = run_phase(sc, a.sc_questions, steps_b, a.warmup)
         lat_b_all = comm.gather_floats(lat_b)
         st = members[0].backend.stats()
+
+        def delta(key):
+            return st.get(key, 0.0) - st_before.get(key, 0.0)
+
         out["self_consistency"] = {
             "metric": f"consensus answers/sec, {names[0]} K={a.k_chains} self-consistency",
             "value": round(n_b / el_b, 3),
@@ -197,6 +202,9 @@ def main() -> None:
             "chains_tokens_per_s": round(n_b * a.k_chains * a.new_tokens / el_b, 1),
             "prefix_cache_hit_rate": round(float(st.get("kv.prefix_hit_rate", 0.0)), 3),
             "cow_copies": int(st.get("kv.cow_copies_total", 0)),
+            "decode_ms_per_step": round(1e3 * delta("decode.seconds") / max(1.0, delta("decode.steps")), 3),
+            "decode_host_ms_per_step": round(1e3 * (delta("decode.seconds") - delta("decode.wait_seconds"))
+                                             / max(1.0, delta("decode.steps")), 3),
         }
     if a.proto_questions > 0:
         # The reference's own topology and loop: four personas share ONE model, a random member

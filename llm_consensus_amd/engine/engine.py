@@ -672,7 +672,10 @@ class Engine:
     def _decode_finish(self, plan, state) -> None:
         g, done, any_decision = state
         if done is not None:
+            t_wait = time.perf_counter()
             done.synchronize()
+            # time the host spent blocked on the GPU; decode.seconds minus this is host work
+            self.metrics.inc("decode.wait_seconds", time.perf_counter() - t_wait)
         B = len(plan.seq_ids)
         tok_h = g.res_tok[:B].numpy().astype(np.int32)
         lp_h = g.res_lp[:B].numpy().astype(np.float32)
