@@ -115,7 +115,8 @@ def build_backend(spec: ModelSpec, device: torch.device, comm=None, tp_rank: int
                  graph_buckets=spec.graph_batch_buckets, name=spec.name,
                  num_kv_blocks=None if device.type == "cuda" else 512)
     tok = make_tokenizer(spec.tokenizer, model.cfg.vocab_size)
-    return EngineBackend(eng, tok, name=spec.name, stop_at_eos=spec.tokenizer is not None)
+    return EngineBackend(eng, tok, name=spec.name, stop_at_eos=spec.tokenizer is not None,
+                         chat_format=spec.chat_format)
 
 
 def build_ensemble(cfg: ConsensusConfig, device: Optional[torch.device] = None,

@@ -57,6 +57,7 @@ class ModelSpec:
     max_prefill_tokens: int = 8192
     graph_batch_buckets: List[int] = field(default_factory=lambda: [1, 2, 4, 8, 16, 32, 64, 128, 256])
     tokenizer: Optional[str] = None   # HF tokenizer dir; None => byte-level fallback
+    chat_format: str = "none"         # none | llama3 | chatml | mistral: turn markers around each prompt
     seed: int = 0                     # random-init seed
 
 

@@ -12,16 +12,18 @@ from typing import Dict, List, Optional, Sequence
 
 from .._native import core
 from ..consensus.backend import Backend, BackendError, GenParams, GenResult, Handle
-from ..utils.tokenizer import Tokenizer
+from ..utils.tokenizer import Tokenizer, apply_chat_format
 from .engine import Engine
 
 
 class EngineBackend(Backend):
     def __init__(self, engine: Engine, tokenizer: Tokenizer, name: Optional[str] = None,
-                 stop_at_eos: bool = True) -> None:
+                 stop_at_eos: bool = True, chat_format: str = "none") -> None:
         self.engine, self.tok = engine, tokenizer
         self.name = name or engine.name
         self.stop_at_eos = stop_at_eos
+        apply_chat_format(chat_format, "")        # validates the name
+        self.chat_format = chat_format
         self._pending: Dict[int, tuple] = {}
 
     def _params(self, p: GenParams) -> "core.SamplingParams":
@@ -30,14 +32,18 @@ class EngineBackend(Backend):
         sp.max_new_tokens, sp.seed = p.max_new_tokens, p.seed
         if self.stop_at_eos and self.tok.eos_id is not None:
             sp.eos_id = self.tok.eos_id
+            sp.stop_ids = [int(i) for i in self.tok.stop_ids]
         else:
             sp.ignore_eos = True
         return sp
 
+    def _wrap(self, prompt: str) -> str:
+        return prompt if self.chat_format == "none" else apply_chat_format(self.chat_format, prompt)
+
     def submit_generate(self, prompt: str, params: GenParams) -> Handle:
         h = Handle()
         try:
-            ids = self.tok.encode(prompt)
+            ids = self.tok.encode(self._wrap(prompt))
             dec = [self.tok.first_token_id(t) for t in params.decision_targets] if params.decision_targets else None
             rid = self.engine.submit(ids, core.RequestKind.Generate, max(1, params.n), self._params(params), dec)
             self._pending[rid] = ("gen", h)
@@ -48,7 +54,7 @@ class EngineBackend(Backend):
     def submit_score(self, prompt: str, targets: Sequence[str]) -> Handle:
         h = Handle()
         try:
-            ids = self.tok.encode(prompt)
+            ids = self.tok.encode(self._wrap(prompt))
             tids = [self.tok.first_token_id(t) for t in targets]
             rid = self.engine.submit(ids, core.RequestKind.Score, score_ids=tids)
             self._pending[rid] = ("score", h)

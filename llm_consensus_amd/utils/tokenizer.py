@@ -12,10 +12,37 @@ from typing import List, Optional, Sequence
 from .._native import core
 
 
+# Prompt wrappers of the instruction-tuned model families the engine loads. The reference
+# delegates this to the remote API's chat endpoint (`client.text_only`,
+# /root/reference/src/main.rs:84); a local model sees raw text and needs its own turn markers.
+CHAT_FORMATS = {
+    "none": "{system}{prompt}",
+    "llama3": "{system}<|start_header_id|>user<|end_header_id|>\n\n{prompt}<|eot_id|>"
+              "<|start_header_id|>assistant<|end_header_id|>\n\n",
+    "chatml": "{system}<|im_start|>user\n{prompt}<|im_end|>\n<|im_start|>assistant\n",
+    "mistral": "[INST] {system}{prompt} [/INST]",
+}
+_SYSTEM_FORMATS = {
+    "none": "{system}\n\n",
+    "llama3": "<|start_header_id|>system<|end_header_id|>\n\n{system}<|eot_id|>",
+    "chatml": "<|im_start|>system\n{system}<|im_end|>\n",
+    "mistral": "{system}\n\n",
+}
+
+
+def apply_chat_format(fmt: str, prompt: str, system: Optional[str] = None) -> str:
+    """Wraps ``prompt`` as one user turn followed by the opening of the assistant turn."""
+    if fmt not in CHAT_FORMATS:
+        raise ValueError(f"unknown chat_format {fmt!r}; known: {sorted(CHAT_FORMATS)}")
+    sys_part = _SYSTEM_FORMATS[fmt].replace("{system}", system) if system else ""
+    return CHAT_FORMATS[fmt].replace("{system}", sys_part).replace("{prompt}", prompt)
+
+
 class Tokenizer:
     bos_id: Optional[int] = None
     eos_id: Optional[int] = None
     vocab_size: int = 0
+    stop_ids: Sequence[int] = ()      # further end-of-turn tokens besides eos_id
 
     def encode(self, text: str, add_bos: bool = True) -> List[int]:
         raise NotImplementedError
@@ -63,7 +90,10 @@ class HFTokenizer(Tokenizer):
         self._t = _Tok.from_file(str(f))
         self.vocab_size = self._t.get_vocab_size()
         self.bos_id = self._find("<|begin_of_text|>", "<s>", "<|im_start|>")
-        self.eos_id = self._find("<|end_of_text|>", "<|eot_id|>", "</s>", "<|im_end|>", "<|endoftext|>")
+        ends = [self._t.token_to_id(n) for n in ("<|end_of_text|>", "<|eot_id|>", "</s>", "<|im_end|>", "<|endoftext|>")]
+        ends = [i for i in ends if i is not None]
+        self.eos_id = ends[0] if ends else None
+        self.stop_ids = tuple(ends[1:])   # e.g. Llama-3 chat turns end with <|eot_id|>, documents with <|end_of_text|>
 
     def _find(self, *names: str) -> Optional[int]:
         for n in names:
