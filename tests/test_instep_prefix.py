@@ -5,6 +5,7 @@ persona text after it (/root/reference/src/main.rs:111-136), so the N personas t
 model submit N prompts with a common head in the same wave. The prefix cache must serve the
 later prompts of a step from the blocks of the earlier ones, and results must not change."""
 import numpy as np
+import pytest
 
 from llm_consensus_amd._native import core
 from llm_consensus_amd.engine.engine import Engine
@@ -105,3 +106,28 @@ def test_engine_results_equal_with_and_without_in_step_sharing():
         assert a.token_ids == b.token_ids
         assert np.allclose(a.decision_logprobs, b.decision_logprobs, atol=2e-4)
     assert np.allclose(s_shared.scores, s_cold.scores, atol=2e-4)
+
+
+@pytest.mark.gpu
+def test_in_step_sharing_on_gpu_matches_cold_prefill():
+    """On the GPU the shared blocks are written by the fused RoPE + KV-write kernel and read by
+    the prefill attention kernel of the SAME step, for a different sequence."""
+    cfg = get_preset("small-llama")
+    model = TransformerModel.random_init(cfg, "cuda", seed=13, std=0.05)
+    head = list(range(5, 5 + 200))
+    prompts = [head + [300 + 7 * i + j for j in range(20 + 3 * i)] for i in range(6)]
+    sp = core.SamplingParams(); sp.max_new_tokens = 6; sp.temperature = 0.0
+    dec = [3, 9, 11]
+
+    def run(cache):
+        eng = Engine(model, num_kv_blocks=256, block_size=64, enable_prefix_cache=cache)
+        rids = [eng.submit(p, params=sp, decision_ids=dec) for p in prompts]
+        eng.run_until_done()
+        return [eng.pop_result(r) for r in rids], eng.stats()
+
+    shared, st = run(True)
+    cold, st_cold = run(False)
+    assert [o.cached_tokens for o in shared] == [0] + [192] * 5 and st_cold["kv.prefix_hit_tokens"] == 0
+    for a, b in zip(shared, cold):
+        assert a.token_ids == b.token_ids
+        assert np.allclose(a.decision_logprobs, b.decision_logprobs, atol=5e-2)
