@@ -109,6 +109,10 @@ class Backend:
         self.run()
         return False
 
+    def fail_pending(self, err: BaseException) -> None:
+        """Completes every outstanding handle with ``err`` (used by drivers that step this
+        backend's engines themselves and caught a failure)."""
+
     def run_local(self) -> None:
         """Compute phase of run(): everything that needs no other backend's ranks."""
         self.run()
@@ -137,8 +141,13 @@ def run_backends(backends: Sequence["Backend"]) -> None:
 
         try:
             run_engines(engines)
-        except Exception:   # the per-backend pass below reports the failure on the right handles
-            pass
+        except Exception as e:  # noqa: BLE001
+            # A step of one engine failed while several were in flight: none of the interleaved
+            # steps can be trusted to have completed, so every engine-backed request of this
+            # batch fails (each backend drops its requests and frees their KV).
+            for b in backends:
+                if b.engines():
+                    b.fail_pending(e)
     for b in backends:
         b.run_local()
     for b in backends:

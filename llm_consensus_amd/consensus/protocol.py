@@ -275,11 +275,16 @@ class SessionPool:
         stepping = [(b, e) for b in self.backends if b.incremental for e in b.engines() if e.has_work()]
         if len(stepping) > 1:
             # steps of different members' engines overlap on their own streams
-            tokens = [(b, e, e.begin_step()) for b, e in stepping]
-            for b, e, tok in tokens:
-                if tok is not None:
-                    e.end_step(tok)
-            for b in {id(b): b for b, _ in stepping}.values():
+            owners = {id(b): b for b, _ in stepping}.values()
+            try:
+                tokens = [(b, e, e.begin_step()) for b, e in stepping]
+                for b, e, tok in tokens:
+                    if tok is not None:
+                        e.end_step(tok)
+            except Exception as err:  # noqa: BLE001  interleaved steps: none can be trusted after a failure
+                for b in owners:
+                    b.fail_pending(err)
+            for b in owners:
                 b.harvest()
             rest = [b for b in self.backends if not b.incremental]
         else:

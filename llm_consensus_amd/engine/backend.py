@@ -12,8 +12,11 @@ from typing import Dict, List, Optional, Sequence
 
 from .._native import core
 from ..consensus.backend import Backend, BackendError, GenParams, GenResult, Handle
+from ..utils.log import get_logger
 from ..utils.tokenizer import Tokenizer, apply_chat_format
 from .engine import Engine
+
+log = get_logger("consensus.engine.backend")
 
 
 class EngineBackend(Backend):
@@ -76,9 +79,9 @@ class EngineBackend(Backend):
     def run(self) -> None:
         try:
             self.engine.run_until_done()
-        except Exception as e:
+        except Exception as e:  # noqa: BLE001  a failed step (HIP / RCCL error, bad shapes) fails its requests only
             self._fail_all(e)
-            raise
+            return
         self._harvest(final=True)
 
     def poll(self) -> bool:
@@ -86,9 +89,9 @@ class EngineBackend(Backend):
         try:
             if self.engine.has_work():
                 self.engine.step()
-        except Exception as e:
+        except Exception as e:  # noqa: BLE001
             self._fail_all(e)
-            raise
+            return False
         self._harvest(final=not self.engine.has_work())
         return bool(self._pending)
 
@@ -98,11 +101,23 @@ class EngineBackend(Backend):
         self._harvest(final=not self.engine.has_work())
         return bool(self._pending)
 
-    def _fail_all(self, e: Exception) -> None:
+    def fail_pending(self, err: BaseException) -> None:
+        self._fail_all(err)
+
+    def _fail_all(self, e: BaseException) -> None:
+        """An engine step raised: every request in flight gets the error (the protocol maps it
+        to its failure policy, main.rs has `.expect()` here and dies), the engine drops them
+        and is ready for new work. The process keeps serving."""
+        log.error("%s: engine step failed, %d request(s) dropped: %s: %s", self.name, len(self._pending),
+                  type(e).__name__, e)
         for rid, (_, h) in self._pending.items():
             if not h.done:
-                h.set_error(BackendError(f"engine failure: {e}"))
+                h.set_error(BackendError(f"engine failure: {type(e).__name__}: {e}"))
         self._pending.clear()
+        try:
+            self.engine.abort_all()
+        except Exception as e2:  # noqa: BLE001
+            log.error("%s: abort after failure failed too: %s", self.name, e2)
 
     def _harvest(self, final: bool) -> None:
         for rid, (kind, h) in list(self._pending.items()):

@@ -428,6 +428,21 @@ class Engine:
     def has_work(self) -> bool:
         return self.sched.has_work()
 
+    def abort_all(self) -> int:
+        """Drops every request the engine holds (waiting, prefilling or decoding) and returns
+        their KV blocks: the recovery path after a failed step, whose requests cannot be
+        resumed because the step's effects on the cache are unknown. Returns how many."""
+        rids = list(self._reqs)
+        for rid in rids:
+            self.sched.abort_request(rid)
+        self.sched.take_finished()
+        self._reqs.clear()
+        self._last_dec = None
+        for g in self._graphs.values():
+            g.rows_key = None
+        self.metrics.inc("requests.aborted", len(rids))
+        return len(rids)
+
     def pop_result(self, rid: int) -> Optional[RequestOutput]:
         return self._done.pop(rid, None)
 
