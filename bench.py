@@ -205,6 +205,8 @@ def main() -> None:
             "decode_ms_per_step": round(1e3 * delta("decode.seconds") / max(1.0, delta("decode.steps")), 3),
             "decode_host_ms_per_step": round(1e3 * (delta("decode.seconds") - delta("decode.wait_seconds"))
                                              / max(1.0, delta("decode.steps")), 3),
+            "decode_host_us_per_step": {k: round(1e6 * delta(f"host.{k}_seconds") / max(1.0, delta("decode.steps")), 1)
+                                        for k in ("schedule", "decode_fill", "decode_launch", "decode_finish")},
         }
     if a.proto_questions > 0:
         # The reference's own topology and loop: four personas share ONE model, a random member

@@ -467,7 +467,9 @@ class Engine:
     def plan_step(self):
         """Asks the scheduler for the next step without launching it (None when idle). The plan
         may be held back by a driver and launched later with ``launch_step``."""
+        t0 = time.perf_counter()
         plan = self.sched.schedule()
+        self.metrics.inc("host.schedule_seconds", time.perf_counter() - t0)
         return None if plan.kind == PK.Idle else plan
 
     def launch_step(self, plan):
@@ -588,6 +590,7 @@ class Engine:
         return B
 
     def _decode_launch(self, plan):
+        t_fill = time.perf_counter()
         B = len(plan.seq_ids)
         gshared = plan.group_shared_blocks
         gcount = plan.group_count
@@ -658,6 +661,8 @@ class Engine:
                     kvb[f:f + c] = int(gshared[gi]) * self.block_size
             put("kv_begin", kvb)
         g.upload()
+        t_launch = time.perf_counter()
+        self.metrics.inc("host.decode_fill_seconds", t_launch - t_fill)
         # ---- run ----
         if self.use_graphs or self.piecewise:
             if g.graph is None and g.pieces is None:
@@ -680,6 +685,7 @@ class Engine:
                 g.res_dec.copy_(dl, non_blocking=True)
             done = torch.cuda.Event()
             done.record()
+            self.metrics.inc("host.decode_launch_seconds", time.perf_counter() - t_launch)
             return g, done, any_decision
         g.res_tok, g.res_lp, g.res_dec = tok, lp, dl
         return g, None, any_decision
@@ -691,6 +697,7 @@ class Engine:
             done.synchronize()
             # time the host spent blocked on the GPU; decode.seconds minus this is host work
             self.metrics.inc("decode.wait_seconds", time.perf_counter() - t_wait)
+        t_fin = time.perf_counter()
         B = len(plan.seq_ids)
         tok_h = g.res_tok[:B].numpy().astype(np.int32)
         lp_h = g.res_lp[:B].numpy().astype(np.float32)
@@ -703,6 +710,7 @@ class Engine:
             self._flush_decisions(keep=cur)
             self._last_dec = cur
         self.sched.complete_decode(plan, tok_h, lp_h)
+        self.metrics.inc("host.decode_finish_seconds", time.perf_counter() - t_fin)
 
     def _flush_decisions(self, keep=None, only_request: Optional[int] = None) -> None:
         """Moves rows of the remembered decode step into their requests' ``decisions``: rows that
