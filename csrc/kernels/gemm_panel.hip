@@ -204,6 +204,138 @@ int launch_panel(int epi, const bf16_t* w, const bf16_t* x, void* Y, const bf16_
   return static_cast<int>(hipGetLastError());
 }
 
+// ---------------------------------------------------------------------------------------------
+// Grouped form for MoE decode steps: blockIdx.z selects an expert; the expert's rows are
+// offsets[e] .. offsets[e+1] of the expert-sorted token list (optionally gathered from X through
+// row_index), its weights start at Wp_all + e * expert_stride. A decode step routes a few dozen
+// tokens to each expert, so every expert's weights are streamed once against one small panel,
+// at the same HBM rate as the dense kernel, instead of through 128x128 tiles built for prefill.
+// BM only has to bound the rows of the busiest expert; the host passes the total row count.
+template <int BM, int EPI>
+__global__ __launch_bounds__(512) void gemm_panel_grouped_kernel(const bf16_t* __restrict__ Wp_all,
+                                                                 long long expert_stride,
+                                                                 const bf16_t* __restrict__ X,
+                                                                 const int32_t* __restrict__ row_index,
+                                                                 const int32_t* __restrict__ offsets,
+                                                                 void* __restrict__ Y, int N, int K, int ldy) {
+  using S = PanelShape<BM, true>;
+  static_assert(S::P * S::DEPTH <= 63, "vmcnt is a 6-bit counter");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int e = blockIdx.z;
+  const int r0 = offsets[e];
+  const int M = min(offsets[e + 1] - r0, BM);
+  if (M <= 0) return;                       // block-uniform: nothing routed to this expert
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wn = wave % S::WN, wm = wave / S::WN;
+  const bf16_t* Wp = Wp_all + static_cast<size_t>(e) * expert_stride;
+  const int KT = K / 32, nk = K / GP_BK, nt0 = static_cast<int>(blockIdx.x) * (GP_BN / 16);
+
+  // Source of this lane's 16-byte chunk in each activation piece it stages (fixed over K).
+  const int rr = lane >> 3, lc = lane & 7;
+  const bf16_t* xsrc[S::XP];
+#pragma unroll
+  for (int q = 0; q < S::XP; ++q) {
+    const int piece = (q * 8 + wave) % (BM / 8);
+    int row = piece * 8 + rr;
+    row = row < M ? row : M - 1;
+    const int grow = row_index ? row_index[r0 + row] : r0 + row;
+    xsrc[q] = X + static_cast<size_t>(grow) * K + ((lc ^ rr) << 3);
+  }
+  auto issue = [&](int t) {
+    if (t >= nk) return;
+    char* stage = smem + (t % S::NSTAGE) * S::STAGE;
+    const bf16_t* src = Wp + (static_cast<size_t>(nt0 + wave) * KT + t * 2) * 512 + lane * 8;
+    char* dst = stage + (wave * 2) * 1024;
+    __builtin_amdgcn_global_load_lds(LC_GLOBAL_PTR(src), LC_LDS_PTR(dst), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds(LC_GLOBAL_PTR(src + 512), LC_LDS_PTR(dst + 1024), 16, 0, 0);
+#pragma unroll
+    for (int q = 0; q < S::XP; ++q) {
+      const int piece = (q * 8 + wave) % (BM / 8);
+      __builtin_amdgcn_global_load_lds(LC_GLOBAL_PTR(xsrc[q] + t * GP_BK),
+                                       LC_LDS_PTR(stage + GP_WBYTES + piece * 1024), 16, 0, 0);
+    }
+  };
+
+  f32x4 acc[S::NT_W][S::MT_W];
+#pragma unroll
+  for (int i = 0; i < S::NT_W; ++i)
+#pragma unroll
+    for (int j = 0; j < S::MT_W; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int t = 0; t < S::DEPTH; ++t) issue(t);
+
+  for (int t = 0; t < nk; ++t) {
+    const int behind = nk - 1 - t;
+    gp_wait_tiles_in_flight<S::P>(behind < S::DEPTH - 1 ? behind : S::DEPTH - 1);
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    issue(t + S::DEPTH);
+    const char* stage = smem + (t % S::NSTAGE) * S::STAGE;
+    const char* wimg = stage + (wn * S::NT_W * 2) * 1024 + lane * 16;
+    const char* ximg = stage + GP_WBYTES;
+    bf16x8 a[S::NT_W][2], b[S::MT_W][2];
+#pragma unroll
+    for (int i = 0; i < S::NT_W; ++i)
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt) a[i][kt] = *reinterpret_cast<const bf16x8*>(wimg + (i * 2 + kt) * 1024);
+#pragma unroll
+    for (int j = 0; j < S::MT_W; ++j)
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt)
+        b[j][kt] = *reinterpret_cast<const bf16x8*>(ximg + gp_x_off(wm * S::MT_W + j, kt, lane));
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int j = 0; j < S::MT_W; ++j)
+#pragma unroll
+        for (int i = 0; i < S::NT_W; ++i)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][kt], b[j][kt], acc[i][j], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+  }
+
+  const int nbase = blockIdx.x * GP_BN + wn * (S::NT_W * 16), mbase = wm * (S::MT_W * 16);
+  // rows of this expert start at r0 in the output; SwiGLU halves the column count
+  bf16_t* Ye = static_cast<bf16_t*>(Y) + static_cast<size_t>(r0) * ldy;
+#pragma unroll
+  for (int i = 0; i < S::NT_W; ++i)
+#pragma unroll
+    for (int j = 0; j < S::MT_W; ++j) {
+      if constexpr (EPI == EPI_SWIGLU) {
+        if (i & 1) continue;
+        store_tile<EPI>(acc[i][j], &acc[(i + 1) % S::NT_W][j], Ye, nullptr, mbase + j * 16, nbase + i * 16, M, N, ldy,
+                        lane, 0);
+      } else {
+        store_tile<EPI>(acc[i][j], nullptr, Ye, nullptr, mbase + j * 16, nbase + i * 16, M, N, ldy, lane, 0);
+      }
+    }
+}
+
+template <int BM>
+int launch_panel_grouped(int epi, const bf16_t* w, long long stride, const bf16_t* x, const int32_t* ri,
+                         const int32_t* off, int E, void* Y, int N, int K, int n_pad, int ldy, hipStream_t stream) {
+  using S = PanelShape<BM, true>;
+  const dim3 grid(n_pad / GP_BN, 1, E), block(512);
+  const int lds = S::NSTAGE * S::STAGE;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_panel_grouped_kernel<BM, EPI_BF16>),
+                        hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_panel_grouped_kernel<BM, EPI_SWIGLU>),
+                        hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    attr_set = true;
+  }
+  if (epi == EPI_BF16)
+    gemm_panel_grouped_kernel<BM, EPI_BF16><<<grid, block, lds, stream>>>(w, stride, x, ri, off, Y, N, K, ldy);
+  else if (epi == EPI_SWIGLU)
+    gemm_panel_grouped_kernel<BM, EPI_SWIGLU><<<grid, block, lds, stream>>>(w, stride, x, ri, off, Y, N, K, ldy);
+  else
+    return -2;
+  return static_cast<int>(hipGetLastError());
+}
+
 }  // namespace
 
 // Y[M<=256, N] = X * W^T. Requirements: K % 64 == 0, (K/64) % splits == 0, n_pad % 128 == 0.
@@ -225,4 +357,21 @@ LC_EXPORT int lc_gemm_panel(const void* Wp, const void* X, void* Y, const void* 
   if (M <= 128) LC_PANEL(128);
   return launch_panel<256, true>(epi, w, x, Y, b, M, N, K, n_pad, ldy, splits, stream);
 #undef LC_PANEL
+}
+
+// Grouped skinny GEMM over E experts (see gemm_panel_grouped_kernel). total_rows <= 256 bounds the
+// rows any single expert can receive. Same row/offset conventions as lc_gemm_grouped.
+LC_EXPORT int lc_gemm_panel_grouped(const void* Wp_all, long long expert_stride, const void* X,
+                                    const void* row_index, const void* offsets, int E, void* Y, int total_rows,
+                                    int N, int K, int n_pad, int ldy, int epi, hipStream_t stream) {
+  if (total_rows <= 0) return 0;
+  if (total_rows > 256 || K % 64 || n_pad % GP_BN || N > n_pad || E < 1) return -1;
+  auto w = static_cast<const bf16_t*>(Wp_all);
+  auto x = static_cast<const bf16_t*>(X);
+  auto ri = static_cast<const int32_t*>(row_index);
+  auto off = static_cast<const int32_t*>(offsets);
+  if (total_rows <= 32) return launch_panel_grouped<32>(epi, w, expert_stride, x, ri, off, E, Y, N, K, n_pad, ldy, stream);
+  if (total_rows <= 64) return launch_panel_grouped<64>(epi, w, expert_stride, x, ri, off, E, Y, N, K, n_pad, ldy, stream);
+  if (total_rows <= 128) return launch_panel_grouped<128>(epi, w, expert_stride, x, ri, off, E, Y, N, K, n_pad, ldy, stream);
+  return launch_panel_grouped<256>(epi, w, expert_stride, x, ri, off, E, Y, N, K, n_pad, ldy, stream);
 }

@@ -356,6 +356,7 @@ def attn_prefill(qkv, k_cache, vt_cache, block_tables, cu_q, ctx_lens, max_q_len
     return out
 
 
+MOE_PANEL_MAX_ROWS = int(os.environ.get("LC_MOE_PANEL_ROWS", "256"))   # routed rows (tokens x top-k) up to which the MoE GEMMs use the panel kernel
 ATTN_PREFIX_WAVES = 4   # 1 = one wave per prefix piece and one partial slot per piece
 
 
@@ -517,11 +518,14 @@ def moe_experts(x: torch.Tensor, ids: torch.Tensor, wts: torch.Tensor, w_gate_up
     partial = E_local != E
     dff = w_gate_up.n // 2
     act = torch.empty(T * topk, dff, dtype=x.dtype, device=dev)
-    h.call("lc_gemm_grouped", w_gate_up.data.data_ptr(), w_gate_up.data[0].numel(), x.data_ptr(),
+    # Decode steps (a few dozen routed rows in total): every expert's weights are streamed once
+    # against one small panel. Prefill-sized batches use the tiled grouped kernel.
+    gg = "lc_gemm_panel_grouped" if T * topk <= MOE_PANEL_MAX_ROWS else "lc_gemm_grouped"
+    h.call(gg, w_gate_up.data.data_ptr(), w_gate_up.data[0].numel(), x.data_ptr(),
            sorted_src.data_ptr(), off_local, E_local, act.data_ptr(), T * topk, w_gate_up.n, w_gate_up.k,
            w_gate_up.n_pad, dff, EPI_SWIGLU)
     y = (torch.zeros if partial else torch.empty)(T * topk, d, dtype=x.dtype, device=dev)
-    h.call("lc_gemm_grouped", w_down.data.data_ptr(), w_down.data[0].numel(), act.data_ptr(), None,
+    h.call(gg, w_down.data.data_ptr(), w_down.data[0].numel(), act.data_ptr(), None,
            off_local, E_local, y.data_ptr(), T * topk, w_down.n, w_down.k, w_down.n_pad, d, EPI_BF16)
     out = torch.empty(T, d, dtype=x.dtype, device=dev)
     h.call("lc_moe_combine", y.data_ptr(), slot_of.data_ptr(), wts.data_ptr(), out.data_ptr(), T, d, topk)

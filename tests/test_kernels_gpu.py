@@ -407,7 +407,7 @@ def test_cosine_medoid_and_judge_kernels_match_host():
 
 
 # ------------------------------------------------------------------ MoE
-@pytest.mark.parametrize("T", [1, 9, 64, 300])
+@pytest.mark.parametrize("T", [1, 9, 24, 64, 100, 300])   # routed rows 2..200: panel kernel (all four panel heights); 600: tiled kernel
 def test_moe_ffn_matches_reference(T):
     d, dff, E, topk = 256, 384, 8, 2
     x = bf(rand(T, d, scale=0.7))
