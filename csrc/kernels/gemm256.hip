@@ -91,11 +91,17 @@ LC_DEVICE int g2_x_off(int kt, int lane) {
     asm volatile("" ::: "memory");           \
   } while (0)
 
-template <int EPI>
+// GROUPED: the rows are the expert-sorted token list of a MoE layer; expert e owns rows
+// offsets[e] .. offsets[e+1] and the weights at Wp + e * expert_stride. m-tiles are numbered
+// through all experts (tiles_m is an upper bound: total_rows / 256 + E); a block walks the E+1
+// offsets to find its expert and leaves if its m-tile is past the last one in use.
+template <int EPI, bool GROUPED = false>
 __global__ __launch_bounds__(512) void gemm256_kernel(const bf16_t* __restrict__ Wp,
                                                       const bf16_t* __restrict__ X, void* __restrict__ Y,
                                                       const bf16_t* __restrict__ bias, int M, int N, int K,
-                                                      int ldy, int tiles_m, int tiles_n) {
+                                                      int ldy, int tiles_m, int tiles_n,
+                                                      long long expert_stride = 0,
+                                                      const int32_t* __restrict__ offsets = nullptr, int E = 0) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -113,7 +119,26 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const bf16_t* __restrict__
   const int bw = min(G2_BAND, tiles_n - band * G2_BAND);
   const int tn = band * G2_BAND + idx % bw, tm = idx / bw;
 
-  G2Ctx c{Wp, X, smem, tn * (G2_BN / 16), tm * G2_BM, M, K, K / 32, K / G2_BK, wave, lane};
+  int m0 = tm * G2_BM;
+  if constexpr (GROUPED) {
+    int gm = tm, e = 0, lo = 0, hi = 0;
+    bool found = false;
+    for (e = 0; e < E; ++e) {
+      lo = offsets[e];
+      hi = offsets[e + 1];
+      const int nt = (hi - lo + G2_BM - 1) / G2_BM;
+      if (gm < nt) {
+        found = true;
+        break;
+      }
+      gm -= nt;
+    }
+    if (!found) return;                      // block-uniform, before any barrier
+    Wp += static_cast<size_t>(e) * expert_stride;
+    m0 = lo + gm * G2_BM;
+    M = hi;                                  // rows of this expert end here (absolute row index)
+  }
+  G2Ctx c{Wp, X, smem, tn * (G2_BN / 16), m0, M, K, K / 32, K / G2_BK, wave, lane};
 
   f32x4 acc[4][8];
 #pragma unroll
@@ -185,7 +210,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const bf16_t* __restrict__
   }
   if (wave < 4) G2_BARRIER();  // balance the stagger barrier
 
-  const int nbase = tn * G2_BN + wn * 64, mbase = tm * G2_BM + wm * 128;
+  const int nbase = tn * G2_BN + wn * 64, mbase = m0 + wm * 128;
   // Epilogue through LDS. Stored straight from the accumulator layout, a wave's store
   // instruction would touch 16 rows with 32 bytes each; the stores of a tile then cost as much
   // as ten K-tiles of math. Instead every wave transposes its sub-tile through a private LDS
@@ -291,6 +316,38 @@ LC_EXPORT int lc_gemm256(const void* Wp, const void* X, void* Y, const void* bia
     gemm256_kernel<EPI_F32><<<grid, block, lds, stream>>>(w, x, Y, b, M, N, K, ldy, tiles_m, tiles_n);
   else if (epi == EPI_SWIGLU)
     gemm256_kernel<EPI_SWIGLU><<<grid, block, lds, stream>>>(w, x, Y, b, M, N, K, ldy, tiles_m, tiles_n);
+  else
+    return -2;
+  LC_RETURN_LAST_ERROR();
+}
+
+// Grouped form over E experts for prefill-sized MoE batches: X [total_rows, K] and Y are in
+// expert-sorted row order, offsets [E+1] delimit the experts' rows. Requirements as lc_gemm256.
+LC_EXPORT int lc_gemm256_grouped(const void* Wp_all, long long expert_stride, const void* X, const void* offsets,
+                                 int E, void* Y, int total_rows, int N, int K, int n_pad, int ldy, int epi,
+                                 hipStream_t stream) {
+  if (total_rows <= 0) return 0;
+  if (K % 64 || n_pad % 256 || N > n_pad || E < 1) return -1;
+  const int tiles_m = (total_rows + G2_BM - 1) / G2_BM + E, tiles_n = n_pad / G2_BN;
+  const dim3 grid(tiles_m * tiles_n), block(512);
+  const size_t lds = 2 * G2_STAGE;
+  auto w = static_cast<const bf16_t*>(Wp_all);
+  auto x = static_cast<const bf16_t*>(X);
+  auto off = static_cast<const int32_t*>(offsets);
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256_kernel<EPI_BF16, true>),
+                        hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+    hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256_kernel<EPI_SWIGLU, true>),
+                        hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+    attr_set = true;
+  }
+  if (epi == EPI_BF16)
+    gemm256_kernel<EPI_BF16, true><<<grid, block, lds, stream>>>(w, x, Y, nullptr, total_rows, N, K, ldy, tiles_m,
+                                                                 tiles_n, expert_stride, off, E);
+  else if (epi == EPI_SWIGLU)
+    gemm256_kernel<EPI_SWIGLU, true><<<grid, block, lds, stream>>>(w, x, Y, nullptr, total_rows, N, K, ldy, tiles_m,
+                                                                   tiles_n, expert_stride, off, E);
   else
     return -2;
   LC_RETURN_LAST_ERROR();

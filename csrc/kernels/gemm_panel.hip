@@ -210,7 +210,7 @@ int launch_panel(int epi, const bf16_t* w, const bf16_t* x, void* Y, const bf16_
 // row_index), its weights start at Wp_all + e * expert_stride. A decode step routes a few dozen
 // tokens to each expert, so every expert's weights are streamed once against one small panel,
 // at the same HBM rate as the dense kernel, instead of through 128x128 tiles built for prefill.
-// BM only has to bound the rows of the busiest expert; the host passes the total row count.
+// The host passes the total row count, which bounds what any one expert can receive.
 template <int BM, int EPI>
 __global__ __launch_bounds__(512) void gemm_panel_grouped_kernel(const bf16_t* __restrict__ Wp_all,
                                                                  long long expert_stride,
@@ -222,9 +222,12 @@ __global__ __launch_bounds__(512) void gemm_panel_grouped_kernel(const bf16_t* _
   static_assert(S::P * S::DEPTH <= 63, "vmcnt is a 6-bit counter");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int e = blockIdx.z;
-  const int r0 = offsets[e];
+  // An expert with more than BM rows is covered by further row blocks (blockIdx.y), each of
+  // which streams the weights again; the host sizes BM at about twice the mean rows per expert
+  // so that this is the exception.
+  const int r0 = offsets[e] + static_cast<int>(blockIdx.y) * BM;
   const int M = min(offsets[e + 1] - r0, BM);
-  if (M <= 0) return;                       // block-uniform: nothing routed to this expert
+  if (M <= 0) return;                       // block-uniform: no (more) rows routed to this expert
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int wn = wave % S::WN, wm = wave / S::WN;
@@ -315,9 +318,10 @@ __global__ __launch_bounds__(512) void gemm_panel_grouped_kernel(const bf16_t* _
 
 template <int BM>
 int launch_panel_grouped(int epi, const bf16_t* w, long long stride, const bf16_t* x, const int32_t* ri,
-                         const int32_t* off, int E, void* Y, int N, int K, int n_pad, int ldy, hipStream_t stream) {
+                         const int32_t* off, int E, int total_rows, void* Y, int N, int K, int n_pad, int ldy,
+                         hipStream_t stream) {
   using S = PanelShape<BM, true>;
-  const dim3 grid(n_pad / GP_BN, 1, E), block(512);
+  const dim3 grid(n_pad / GP_BN, (total_rows + BM - 1) / BM, E), block(512);
   const int lds = S::NSTAGE * S::STAGE;
   static bool attr_set = false;
   if (!attr_set) {
@@ -365,13 +369,18 @@ LC_EXPORT int lc_gemm_panel_grouped(const void* Wp_all, long long expert_stride,
                                     const void* row_index, const void* offsets, int E, void* Y, int total_rows,
                                     int N, int K, int n_pad, int ldy, int epi, hipStream_t stream) {
   if (total_rows <= 0) return 0;
-  if (total_rows > 256 || K % 64 || n_pad % GP_BN || N > n_pad || E < 1) return -1;
+  if (K % 64 || n_pad % GP_BN || N > n_pad || E < 1) return -1;
   auto w = static_cast<const bf16_t*>(Wp_all);
   auto x = static_cast<const bf16_t*>(X);
   auto ri = static_cast<const int32_t*>(row_index);
   auto off = static_cast<const int32_t*>(offsets);
-  if (total_rows <= 32) return launch_panel_grouped<32>(epi, w, expert_stride, x, ri, off, E, Y, N, K, n_pad, ldy, stream);
-  if (total_rows <= 64) return launch_panel_grouped<64>(epi, w, expert_stride, x, ri, off, E, Y, N, K, n_pad, ldy, stream);
-  if (total_rows <= 128) return launch_panel_grouped<128>(epi, w, expert_stride, x, ri, off, E, Y, N, K, n_pad, ldy, stream);
-  return launch_panel_grouped<256>(epi, w, expert_stride, x, ri, off, E, Y, N, K, n_pad, ldy, stream);
+  // Panel height: about twice the mean rows per expert (the routing of a batch is never even).
+  const int want = std::min(total_rows, std::max(32, 2 * ((total_rows + E - 1) / E)));
+#define LC_PG(BM_) \
+  return launch_panel_grouped<BM_>(epi, w, expert_stride, x, ri, off, E, total_rows, Y, N, K, n_pad, ldy, stream)
+  if (want <= 32) LC_PG(32);
+  if (want <= 64) LC_PG(64);
+  if (want <= 128) LC_PG(128);
+  LC_PG(256);
+#undef LC_PG
 }

@@ -356,7 +356,8 @@ def attn_prefill(qkv, k_cache, vt_cache, block_tables, cu_q, ctx_lens, max_q_len
     return out
 
 
-MOE_PANEL_MAX_ROWS = int(os.environ.get("LC_MOE_PANEL_ROWS", "256"))   # routed rows (tokens x top-k) up to which the MoE GEMMs use the panel kernel
+MOE_PANEL_MAX_ROWS = int(os.environ.get("LC_MOE_PANEL_ROWS", "640"))   # routed rows (tokens x top-k) up to which the MoE GEMMs use the panel kernel
+MOE_GEMM256_MIN_ROWS = int(os.environ.get("LC_MOE_G256_ROWS", "641"))   # routed rows from which the 256x256 grouped GEMM is used
 ATTN_PREFIX_WAVES = 4   # 1 = one wave per prefix piece and one partial slot per piece
 
 
@@ -521,6 +522,20 @@ def moe_experts(x: torch.Tensor, ids: torch.Tensor, wts: torch.Tensor, w_gate_up
     # Decode steps (a few dozen routed rows in total): every expert's weights are streamed once
     # against one small panel. Prefill-sized batches use the tiled grouped kernel.
     gg = "lc_gemm_panel_grouped" if T * topk <= MOE_PANEL_MAX_ROWS else "lc_gemm_grouped"
+    if (gg == "lc_gemm_grouped" and T * topk >= MOE_GEMM256_MIN_ROWS and w_gate_up.n_pad % 256 == 0
+            and w_down.n_pad % 256 == 0 and w_gate_up.k % 64 == 0 and w_down.k % 64 == 0):
+        # Prefill-sized batches: the 256x256 pipelined tile per expert. It reads contiguous rows,
+        # so the tokens are first gathered into expert order (a copy of T*topk rows, a fraction
+        # of a percent of the GEMMs' time).
+        xs = embed(sorted_src, x)
+        h.call("lc_gemm256_grouped", w_gate_up.data.data_ptr(), w_gate_up.data[0].numel(), xs.data_ptr(), off_local,
+               E_local, act.data_ptr(), T * topk, w_gate_up.n, w_gate_up.k, w_gate_up.n_pad, dff, EPI_SWIGLU)
+        y = (torch.zeros if partial else torch.empty)(T * topk, d, dtype=x.dtype, device=dev)
+        h.call("lc_gemm256_grouped", w_down.data.data_ptr(), w_down.data[0].numel(), act.data_ptr(), off_local,
+               E_local, y.data_ptr(), T * topk, w_down.n, w_down.k, w_down.n_pad, d, EPI_BF16)
+        out = torch.empty(T, d, dtype=x.dtype, device=dev)
+        h.call("lc_moe_combine", y.data_ptr(), slot_of.data_ptr(), wts.data_ptr(), out.data_ptr(), T, d, topk)
+        return out
     h.call(gg, w_gate_up.data.data_ptr(), w_gate_up.data[0].numel(), x.data_ptr(),
            sorted_src.data_ptr(), off_local, E_local, act.data_ptr(), T * topk, w_gate_up.n, w_gate_up.k,
            w_gate_up.n_pad, dff, EPI_SWIGLU)
