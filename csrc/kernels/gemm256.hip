@@ -38,13 +38,14 @@ struct G2Ctx {
   const bf16_t* __restrict__ X;
   char* smem;
   int nt0, m0, M, K, KT, nk, wave, lane;
+  int kt_lo = 0;   // first K-tile of this block's K split
 };
 
 // Issues this wave's two 1-KiB pieces of half `which` (0:W0 1:W1 2:X0 3:X1) of K-tile kt_tile.
 LC_DEVICE void g2_issue_half(const G2Ctx& c, int k_tile, int which) {
   if (k_tile >= c.nk) return;
   char* stage = c.smem + (k_tile & 1) * G2_STAGE;
-  const int kt0 = k_tile * 2;
+  const int kt0 = (c.kt_lo + k_tile) * 2;
   const int tile = (which & 1) * 8 + c.wave;  // 16-row tile inside the 256-row operand panel
   if (which < 2) {
     const bf16_t* src = c.Wp + (static_cast<size_t>(c.nt0 + tile) * c.KT + kt0) * 512 + c.lane * 8;
@@ -101,7 +102,8 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const bf16_t* __restrict__
                                                       const bf16_t* __restrict__ bias, int M, int N, int K,
                                                       int ldy, int tiles_m, int tiles_n,
                                                       long long expert_stride = 0,
-                                                      const int32_t* __restrict__ offsets = nullptr, int E = 0) {
+                                                      const int32_t* __restrict__ offsets = nullptr, int E = 0,
+                                                      int nk_per_split = 0) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -139,6 +141,10 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const bf16_t* __restrict__
     M = hi;                                  // rows of this expert end here (absolute row index)
   }
   G2Ctx c{Wp, X, smem, tn * (G2_BN / 16), m0, M, K, K / 32, K / G2_BK, wave, lane};
+  if (nk_per_split > 0) {   // split-K (blockIdx.y): fp32 slabs, summed by the consumer or by lc_splitk_reduce
+    c.nk = nk_per_split;
+    c.kt_lo = static_cast<int>(blockIdx.y) * nk_per_split;
+  }
 
   f32x4 acc[4][8];
 #pragma unroll
@@ -281,7 +287,9 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const bf16_t* __restrict__
         if (i & 1) continue;
         store_tile<EPI>(acc[i][j], &acc[i + 1][j], Y, bias, mbase + j * 16, nbase + i * 16, M, N, ldy, lane, 0);
       } else {
-        store_tile<EPI>(acc[i][j], nullptr, Y, bias, mbase + j * 16, nbase + i * 16, M, N, ldy, lane, 0);
+        const size_t slab = (EPI == EPI_F32) ? static_cast<size_t>(blockIdx.y) * M * ldy : 0;
+        store_tile<EPI>(acc[i][j], nullptr, Y, gridDim.y > 1 ? nullptr : bias, mbase + j * 16, nbase + i * 16, M, N,
+                        ldy, lane, slab);
       }
     }
 }
@@ -290,6 +298,9 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const bf16_t* __restrict__
 }  // namespace
 
 // Y = X * W^T with the 256x256 pipelined tile. Requirements: K % 64 == 0, n_pad % 256 == 0.
+LC_EXPORT int lc_gemm256_splitk(const void* Wp, const void* X, void* Y, int M, int N, int K, int n_pad, int ldy,
+                                int splits, hipStream_t stream);
+
 LC_EXPORT int lc_gemm256(const void* Wp, const void* X, void* Y, const void* bias, int M, int N, int K,
                          int n_pad, int ldy, int epi, hipStream_t stream) {
   if (M <= 0) return 0;
@@ -350,5 +361,26 @@ LC_EXPORT int lc_gemm256_grouped(const void* Wp_all, long long expert_stride, co
                                                                    tiles_n, expert_stride, off, E);
   else
     return -2;
+  LC_RETURN_LAST_ERROR();
+}
+
+// Split-K form for a few hundred to a few thousand rows against a narrow output, where the
+// 256x256 tiles alone would leave most CUs idle: Y = fp32 slabs [splits, M, ldy] (no bias).
+LC_EXPORT int lc_gemm256_splitk(const void* Wp, const void* X, void* Y, int M, int N, int K, int n_pad, int ldy,
+                                int splits, hipStream_t stream) {
+  if (M <= 0) return 0;
+  if (K % 64 || n_pad % 256 || N > n_pad || splits < 1 || (K / G2_BK) % splits) return -1;
+  const int tiles_m = (M + G2_BM - 1) / G2_BM, tiles_n = n_pad / G2_BN;
+  const dim3 grid(tiles_m * tiles_n, splits), block(512);
+  const size_t lds = 2 * G2_STAGE;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256_kernel<EPI_F32>),
+                        hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+    attr_set = true;
+  }
+  gemm256_kernel<EPI_F32><<<grid, block, lds, stream>>>(static_cast<const bf16_t*>(Wp), static_cast<const bf16_t*>(X), Y,
+                                                        nullptr, M, N, K, ldy, tiles_m, tiles_n, 0, nullptr, 0,
+                                                        (K / G2_BK) / splits);
   LC_RETURN_LAST_ERROR();
 }

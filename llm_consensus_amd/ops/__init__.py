@@ -166,6 +166,22 @@ def _choose_panel_splits(n_pad: int, K: int) -> int:
     return best
 
 
+def _choose_gemm256_splits(tiles: int, K: int) -> int:
+    """K splits for the 256x256 kernel when its tiles alone cover less than half of the CUs:
+    the most splits that keep tiles * splits within the 256 CUs, in whole 64-deep K-tiles, at
+    least 8 of them each (below that the pipeline's fill and the slab traffic dominate)."""
+    if tiles * 2 > 256 or GEMM256_MAX_SPLITS <= 1:
+        return 1
+    nk = K // 64
+    best = 1
+    for s in (2, 3, 4, 6, 7, 8):
+        if tiles * s > 256 or s > GEMM256_MAX_SPLITS:
+            break
+        if nk % s == 0 and nk // s >= 8:
+            best = s
+    return best
+
+
 @dataclass
 class PartialSum:
     """Un-reduced output of a split-K GEMM: ``part`` holds S fp32 slabs [S, M, N] whose sum
@@ -210,6 +226,17 @@ def linear(x: torch.Tensor, w: LinearWeight, out_f32: bool = False, defer_reduce
         return y
     if M > WS_MAX_M:
         tiles256 = ((M + 255) // 256) * (w.n_pad // 256)
+        splits = _choose_gemm256_splits(tiles256, w.k) if (w.n_pad % 256 == 0 and not w.swiglu) else 1
+        if splits > 1 and GEMM256_MIN_TILES >= 0:
+            # Too few 256x256 tiles to fill the chip (a few hundred rows, narrow output): split K.
+            part = torch.empty(splits, M, w.n, dtype=torch.float32, device=x.device)
+            h.call("lc_gemm256_splitk", w.data.data_ptr(), x.data_ptr(), part.data_ptr(), M, w.n, w.k, w.n_pad, w.n,
+                   splits)
+            if defer_reduce and not out_f32:
+                return PartialSum(part, w.bias)
+            h.call("lc_splitk_reduce", part.data_ptr(), h.ptr(w.bias), y.data_ptr(), splits, M, w.n, out_n,
+                   1 if out_f32 else 0)
+            return y
         if GEMM256_MIN_TILES >= 0 and w.n_pad % 256 == 0 and tiles256 >= GEMM256_MIN_TILES:
             h.call("lc_gemm256", w.data.data_ptr(), x.data_ptr(), y.data_ptr(), h.ptr(w.bias), M, w.n, w.k, w.n_pad,
                    out_n, epi)
@@ -358,6 +385,7 @@ def attn_prefill(qkv, k_cache, vt_cache, block_tables, cu_q, ctx_lens, max_q_len
 
 MOE_PANEL_MAX_ROWS = int(os.environ.get("LC_MOE_PANEL_ROWS", "640"))   # routed rows (tokens x top-k) up to which the MoE GEMMs use the panel kernel
 MOE_GEMM256_MIN_ROWS = int(os.environ.get("LC_MOE_G256_ROWS", "641"))   # routed rows from which the 256x256 grouped GEMM is used
+GEMM256_MAX_SPLITS = int(os.environ.get("LC_G256_SPLITS", "8"))
 ATTN_PREFIX_WAVES = 4   # 1 = one wave per prefix piece and one partial slot per piece
 
 

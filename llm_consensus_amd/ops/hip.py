@@ -30,6 +30,7 @@ _SIGNATURES = {
     "lc_kgemm": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
     "lc_splitk_reduce": [_P, _P, _P, _I, _I, _I, _I, _I, _P],
     "lc_gemm_grouped": [_P, _L, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _P],
+    "lc_gemm256_splitk": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "lc_gemm256_grouped": [_P, _L, _P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _P],
     "lc_gemm_panel_grouped": [_P, _L, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _P],
     "lc_rope_kv_write": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _I, _P, _P],
