@@ -58,13 +58,19 @@ def _hip():
 
 
 # ---------------------------------------------------------------------------- weights
+def padded_rows(N: int) -> int:
+    """Output rows are padded with zeros to whole column tiles: 256 (so the 256x256 prefill
+    kernel and its split-K / grouped forms apply to every projection), 128 for tiny outputs."""
+    return (N + 127) // 128 * 128 if N <= 128 else (N + 255) // 256 * 256
+
+
 def pack_weight(W: torch.Tensor) -> torch.Tensor:
     """[N, K] row-major -> MFMA-fragment order [n_pad/16, K/32, 64, 8] (see gemm.hip):
     packed[nt, kt, lane, j] = W[nt*16 + (lane & 15), kt*32 + 8*(lane >> 4) + j]."""
     N, K = W.shape
     if K % 64:
         raise ValueError(f"K={K} must be a multiple of 64")
-    n_pad = (N + 127) // 128 * 128
+    n_pad = padded_rows(N)
     if n_pad != N:
         W = torch.cat([W, W.new_zeros(n_pad - N, K)], 0)
     return W.view(n_pad // 16, 16, K // 32, 4, 8).permute(0, 2, 3, 1, 4).contiguous().view(n_pad // 16, K // 32, 64, 8)
@@ -96,7 +102,7 @@ class LinearWeight:
 
     @property
     def n_pad(self) -> int:
-        return (self.n + 127) // 128 * 128
+        return padded_rows(self.n)
 
     @property
     def is_packed(self) -> bool:
@@ -487,7 +493,7 @@ class ExpertWeights:
 
     @property
     def n_pad(self) -> int:
-        return (self.n + 127) // 128 * 128
+        return padded_rows(self.n)
 
     @classmethod
     def from_dense(cls, W: torch.Tensor, device=None, swiglu: bool = False):
