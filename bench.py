@@ -200,8 +200,12 @@ def main() -> None:
             "p50_latency_ms": round(float(np.percentile(lat_b_all, 50)), 1),
             "p95_latency_ms": round(float(np.percentile(lat_b_all, 95)), 1),
             "chains_tokens_per_s": round(n_b * a.k_chains * a.new_tokens / el_b, 1),
-            "prefix_cache_hit_rate": round(float(st.get("kv.prefix_hit_rate", 0.0)), 3),
-            "cow_copies": int(st.get("kv.cow_copies_total", 0)),
+            # the K chains of a question are forks of one prefilled prompt: they attend ONE copy of
+            # its full KV blocks (shared-prefix decode kernel); the prefix cache is not involved
+            "chains_per_question": a.k_chains,
+            "prompt_kv_blocks_shared_by_the_chains": a.prompt_len // bs,
+            "prompt_kv_reads_saved": round(1.0 - 1.0 / a.k_chains, 3),
+            "cow_copies": int(delta("kv.cow_copies_total")),
             "decode_ms_per_step": round(1e3 * delta("decode.seconds") / max(1.0, delta("decode.steps")), 3),
             "decode_host_ms_per_step": round(1e3 * (delta("decode.seconds") - delta("decode.wait_seconds"))
                                              / max(1.0, delta("decode.steps")), 3),
