@@ -79,7 +79,7 @@ def main():
                     row[v + "_TBs"] = round(nbytes / us / 1e6, 2)
                 except Exception as ex:  # noqa: BLE001
                     row[v + "_err"] = str(ex)[:80]
-                ops.WS_MAX_M, ops.GEMM256_MIN_TILES = 256, 192
+                ops.WS_MAX_M, ops.GEMM256_MIN_TILES = 256, 1
                 ops.DECODE_KERNEL = "panel"
             out.append(row)
             print(row, flush=True)

@@ -72,7 +72,7 @@ def bench_gemm(results):
                 row[name + "_us"] = round(us, 2)
                 row[name + "_tflops"] = round(2 * M * N * K / us / 1e6, 1)
                 row[name + "_gbs"] = round((N * K * 2 + M * K * 2 + M * N * 2) / us / 1e3, 1)
-            ops.WS_MAX_M, ops.GEMM256_MIN_TILES, ops.KGEMM_FORCE_NTW = 256, 192, -1
+            ops.WS_MAX_M, ops.GEMM256_MIN_TILES, ops.KGEMM_FORCE_NTW = 256, 1, -1
             us = timeit(lambda: X @ W.t())
             row["torch_us"] = round(us, 2)
             row["torch_tflops"] = round(2 * M * N * K / us / 1e6, 1)

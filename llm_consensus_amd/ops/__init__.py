@@ -19,9 +19,11 @@ EPI_BF16, EPI_F32, EPI_SWIGLU = 0, 1, 2
 
 # M at or below which the weight-streaming kernel is used instead of the 128x128 tile kernel.
 WS_MAX_M = int(os.environ.get("LC_WS_MAX_M", "256"))
-# The 256x256 pipelined kernel runs one workgroup per CU: use it once a launch has at least this
-# many 256x256 tiles (fewer tiles leave CUs idle; the 128x128 kernel fills the chip better). -1 disables.
-GEMM256_MIN_TILES = int(os.environ.get("LC_GEMM256_MIN_TILES", "192"))
+# Fewest 256x256 tiles for which the 256x256 pipelined kernel is used. It beats the 128x128 kernel
+# even when its tiles cover a third of the CUs (160 tiles: 171 vs 308 us, 80 tiles: 145 vs 155 us at
+# K = 8192), and below half coverage its split-K form takes over, so the default is "always".
+# -1 disables the kernel (128x128 tiles everywhere).
+GEMM256_MIN_TILES = int(os.environ.get("LC_GEMM256_MIN_TILES", "1"))
 # Decode GEMM for 17..256 rows: "panel" (gemm_panel.hip, deep LDS-DMA ring) or "ws" (weight-streaming
 # wsgemm in gemm.hip, kept for comparison), and the panel kernel's split-K policy.
 DECODE_KERNEL = os.environ.get("LC_DECODE_KERNEL", "panel")
