@@ -38,10 +38,10 @@ LC_DEVICE ArgMax argmax_combine(ArgMax a, ArgMax b) {
 template <typename F>
 LC_DEVICE void for_each_strided(const float* __restrict__ row, int V, bool vec, F&& f) {
   if (vec) {
-    // Four independent 16-byte loads are issued before any of them is consumed: with one
+    // Eight independent 16-byte loads are issued before any of them is consumed: with one
     // block per row a CU has few waves, and a load-use-load chain leaves it latency-bound at
     // a fraction of what the L2 can deliver.
-    constexpr int U = 4, STEP = kThreads * 4;
+    constexpr int U = 8, STEP = kThreads * 4;
     int i = threadIdx.x * 4;
     for (; i + (U - 1) * STEP < V; i += U * STEP) {
       f32x4 v[U];
@@ -88,9 +88,21 @@ __global__ __launch_bounds__(kThreads) void sample_kernel(
   const bool greedy = !(T > 0.f);
   const float inv_t = greedy ? 1.f : 1.f / T;
 
-  // ---- pass 1: arg-max of z = logit / T ----
+  // ---- pass 1: arg-max of z = logit / T and, in the same sweep, the partition function ----
+  // Every thread keeps a running maximum m and the sum of exp(z - m) over what it has seen
+  // (rescaled whenever m grows); the block then rebases the per-thread sums on the global max.
   ArgMax am{-INFINITY, 0x7fffffff};
-  for_each_strided(row, V, vec, [&](float x, int i) { am = argmax_combine(am, ArgMax{x * inv_t, i}); });
+  float run_m = -INFINITY, run_s = 0.f;
+  for_each_strided(row, V, vec, [&](float x, int i) {
+    const float z = x * inv_t;
+    am = argmax_combine(am, ArgMax{z, i});
+    if (z > run_m) {
+      run_s = run_s * __expf(run_m - z) + 1.f;     // exp(-inf) = 0 on the first element
+      run_m = z;
+    } else if (z > -INFINITY) {                    // -inf pads (ragged vocabulary shards) carry no mass
+      run_s += __expf(z - run_m);
+    }
+  });
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1)
     am = argmax_combine(am, ArgMax{__shfl_xor(am.v, off, 64), __shfl_xor(am.i, off, 64)});
@@ -102,11 +114,7 @@ __global__ __launch_bounds__(kThreads) void sample_kernel(
   am = ArgMax{sv[0], si[0]};
   for (int i = 1; i < kWaves; ++i) am = argmax_combine(am, ArgMax{sv[i], si[i]});
   const float zmax = am.v;
-
-  // ---- pass 2: partition function (relative to zmax) ----
-  float tsum = 0.f;
-  for_each_strided(row, V, vec, [&](float x, int) { tsum += __expf(x * inv_t - zmax); });
-  const float total = block_sum(tsum, red);
+  const float total = block_sum(run_m > -INFINITY ? run_s * __expf(run_m - zmax) : 0.f, red);
   if (greedy) {
     if (threadIdx.x == 0) {
       out_token[r] = am.i;
@@ -127,17 +135,23 @@ __global__ __launch_bounds__(kThreads) void sample_kernel(
     float lo = fmaxf(thr, zmax - 30.f), hi = zmax;
     const float target = phase == 0 ? static_cast<float>(k) : p * kept_mass;
     bool found = false;
+    // Mass (or count) of the entries at or above `hi`. While hi is still the row maximum those
+    // entries are binned with the rest (top bin); once the search has moved to an interior
+    // interval they are known from the sweep that excluded them and are skipped: a sweep after
+    // the first touches its histogram only for the ~1/12 of the candidates still in range.
+    float above = 0.f;
+    bool hi_is_max = true;
     for (int it = 0; it < kSearchPasses; ++it) {
       // Per-thread histogram over kBins equal sub-intervals of [lo, hi): thread t owns column t
-      // of hist[kBins][kThreads] (conflict-free, no atomics). Entries >= hi land in the top bin,
-      // so suffix sums give the mass (or count) above each threshold t_j = lo + w*j.
+      // of hist[kBins][kThreads] (conflict-free, no atomics), so suffix sums give the mass (or
+      // count) above each threshold t_j = lo + w*j.
       const float w = (hi - lo) * (1.f / kBins);
       const float inv_w = w > 0.f ? 1.f / w : 0.f;
 #pragma unroll
       for (int j = 0; j < kBins; ++j) hist[j * kThreads + threadIdx.x] = 0.f;
       for_each_strided(row, V, vec, [&](float x, int) {
         const float z = x * inv_t;
-        if (z >= lo) {
+        if (z >= lo && (hi_is_max || z < hi)) {
           int b = static_cast<int>((z - lo) * inv_w);
           b = b < kBins - 1 ? b : kBins - 1;
           hist[b * kThreads + threadIdx.x] += phase == 0 ? 1.f : __expf(z - zmax);
@@ -154,19 +168,24 @@ __global__ __launch_bounds__(kThreads) void sample_kernel(
       __syncthreads();
       // every thread walks the thresholds from the top; the result is block-uniform
       int best = -1;
-      float cum = 0.f, best_v = 0.f;
+      float cum = above, best_v = 0.f, above_best = above;
       for (int j = kBins - 1; j >= 0 && best < 0; --j) {
+        const float before = cum;
         for (int wv = 0; wv < kWaves; ++wv) cum += multi[wv][j];
         if (cum >= target) {
           best = j;
           best_v = cum;
+          above_best = before;
         }
       }
       if (best < 0) break;  // even {z >= lo} misses the target: keep the previous edge
       const float nlo = lo + w * static_cast<float>(best);
-      const float nhi = best >= kBins - 1 ? hi : lo + w * static_cast<float>(best + 1);
+      if (best < kBins - 1) {
+        hi = lo + w * static_cast<float>(best + 1);
+        hi_is_max = false;
+        above = above_best;
+      }
       lo = nlo;
-      hi = nhi;
       thr = lo;
       found = true;
       if (phase == 0 && best_v == target) break;
