@@ -26,10 +26,16 @@
 // split (EPI_F32 slabs, summed by the consumer or by lc_splitk_reduce) so that narrow
 // outputs still fill the chip.
 #include "gemm_common.h"
+#include <type_traits>
 
 namespace {
 
 constexpr int GP_BN = 128, GP_BK = 64, GP_WBYTES = 16 * 1024;
+// Cache policy of the weight loads: non-temporal. Every weight byte is read exactly once per
+// launch while the activation panel is re-read by every workgroup, so the weights should pass
+// through L2 without displacing it: measured 41.6 vs 48.5 us (5.65 vs 4.84 TB/s) on a
+// 28672 x 4096 matrix at 32 rows, and 4-9 % on the narrower projections.
+constexpr int GP_NT = 2;
 
 // DEEP = true: the ring takes (almost) all of a CU's LDS, one workgroup per CU, most loads in
 // flight -- best when the GEMM has the GPU to itself. DEEP = false: a ring of three stages
@@ -45,6 +51,7 @@ struct PanelShape {
   static constexpr int MT_W = (BM / 16) / WM;              // m-tiles per wave
   static constexpr int XP = BM / 8 >= 8 ? BM / 64 : 1;     // X pieces a wave issues per K-tile
   static constexpr int P = 2 + XP;                         // DMA instructions per wave per K-tile
+  static constexpr bool PIPE = BM >= 256;                  // fragments double-buffered in registers
 };
 
 struct GpCtx {
@@ -54,17 +61,17 @@ struct GpCtx {
   int nt0, M, K, KT, kt_lo, nk, wave, lane;
 };
 
-template <int BM, bool DEEP>
+template <int BM, bool DEEP, bool UNCHECKED = false>
 LC_DEVICE void gp_issue_tile(const GpCtx& c, int t) {
   using S = PanelShape<BM, DEEP>;
-  if (t >= c.nk) return;
+  if (!UNCHECKED && t >= c.nk) return;
   char* stage = c.smem + (t % S::NSTAGE) * S::STAGE;
   const int k_tile = c.kt_lo + t;
   {
     const bf16_t* src = c.Wp + (static_cast<size_t>(c.nt0 + c.wave) * c.KT + k_tile * 2) * 512 + c.lane * 8;
     char* dst = stage + (c.wave * 2) * 1024;
-    __builtin_amdgcn_global_load_lds(LC_GLOBAL_PTR(src), LC_LDS_PTR(dst), 16, 0, 0);
-    __builtin_amdgcn_global_load_lds(LC_GLOBAL_PTR(src + 512), LC_LDS_PTR(dst + 1024), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds(LC_GLOBAL_PTR(src), LC_LDS_PTR(dst), 16, 0, GP_NT);
+    __builtin_amdgcn_global_load_lds(LC_GLOBAL_PTR(src + 512), LC_LDS_PTR(dst + 1024), 16, 0, GP_NT);
   }
   // Activations: pieces of 8 rows x 128 B. The LDS image of a DMA is lane-linear, so the XOR
   // swizzle that keeps the fragment reads off each other's banks is applied on the source
@@ -122,6 +129,93 @@ __global__ __launch_bounds__(512) void gemm_panel_kernel(const bf16_t* __restric
 #pragma unroll
     for (int j = 0; j < S::MT_W; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+  if constexpr (S::PIPE) {
+    // BM = 256: a K-tile costs a wave 32 MFMAs, 16 fragment reads and 6 DMA issues, and with two
+    // waves per SIMD in step at the barrier those three phases would run one after the other.
+    // Here the fragments live in two register sets: while the MFMAs of K-tile t run from one set,
+    // the reads of K-tile t+1 fill the other, and the DMA issues sit between them. A stage is
+    // free as soon as its fragments are in registers, so all NSTAGE stages hold tiles in flight.
+    bf16x8 fa[2][S::NT_W][2], fb[2][S::MT_W][2];
+    auto read_frags = [&](int t, int set) __attribute__((always_inline)) {
+      const char* stage = smem + (t % S::NSTAGE) * S::STAGE;
+      const char* wimg = stage + (wn * S::NT_W * 2) * 1024 + lane * 16;
+      const char* ximg = stage + GP_WBYTES;
+#pragma unroll
+      for (int i = 0; i < S::NT_W; ++i)
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+          fa[set][i][kt] = *reinterpret_cast<const bf16x8*>(wimg + (i * 2 + kt) * 1024);
+#pragma unroll
+      for (int j = 0; j < S::MT_W; ++j)
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+          fb[set][j][kt] = *reinterpret_cast<const bf16x8*>(ximg + gp_x_off(wm * S::MT_W + j, kt, lane));
+    };
+    // MAIN steps (t + NSTAGE < nk) have nothing conditional in them: one basic block, so the
+    // scheduler can be told to spread the fragment reads and the DMA issues between the MFMAs.
+    auto step = [&](int t, auto set_c, auto main_c) __attribute__((always_inline)) {
+      constexpr int set = decltype(set_c)::value;
+      constexpr bool MAIN = decltype(main_c)::value;
+      // K-tile t+1 has landed (this wave's pieces; the barrier extends that to everybody's), and
+      // this wave's reads of K-tile t are complete, so after the barrier stage t % NSTAGE is free.
+      const int after = c.nk - 2 - t;    // K-tiles beyond t+1 that exist
+      if constexpr (MAIN) {
+        gp_wait_tiles_in_flight<S::P>(S::NSTAGE - 2);
+      } else {
+        if (after >= 0) gp_wait_tiles_in_flight<S::P>(after < S::NSTAGE - 2 ? after : S::NSTAGE - 2);
+      }
+      __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0): the fragment reads issued one step ago
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      if (MAIN || after >= 0) read_frags(t + 1, set ^ 1);
+      if (MAIN || t + S::NSTAGE < c.nk) gp_issue_tile<BM, DEEP, true>(c, t + S::NSTAGE);
+      if constexpr (!MAIN) __builtin_amdgcn_s_setprio(1);   // (a priority change would pin the schedule)
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int j = 0; j < S::MT_W; ++j)
+#pragma unroll
+          for (int i = 0; i < S::NT_W; ++i)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[set][i][kt], fb[set][j][kt], acc[i][j], 0, 0, 0);
+      if constexpr (!MAIN) __builtin_amdgcn_s_setprio(0);
+      if constexpr (MAIN) {
+        // One memory instruction (DMA issue or fragment read; both count as LDS instructions
+        // for the scheduler), then one MFMA early on and two towards the end, where the reads
+        // that the next step waits for should already be on their way.
+        constexpr int N_MFMA = 2 * S::MT_W * S::NT_W, N_MEM = 2 * (S::MT_W + S::NT_W) + S::P;
+        constexpr int N_DOUBLE = N_MFMA - N_MEM;     // groups that get two MFMAs
+        static_assert(N_DOUBLE >= 0 && N_DOUBLE <= N_MEM, "between one and two MFMAs per memory instruction");
+#pragma unroll
+        for (int g = 0; g < N_MEM - N_DOUBLE; ++g) {
+          __builtin_amdgcn_sched_group_barrier(0x130, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        }
+#pragma unroll
+        for (int g = 0; g < N_DOUBLE; ++g) {
+          __builtin_amdgcn_sched_group_barrier(0x130, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+        }
+      }
+    };
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+#pragma unroll
+    for (int t = 0; t < S::NSTAGE; ++t) gp_issue_tile<BM, DEEP>(c, t);
+    gp_wait_tiles_in_flight<S::P>(c.nk - 1 < S::NSTAGE - 1 ? c.nk - 1 : S::NSTAGE - 1);
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    read_frags(0, 0);
+    int t = 0;
+    for (; t + 1 + S::NSTAGE < c.nk; t += 2) {
+      step(t, I0{}, std::true_type{});
+      step(t + 1, I1{}, std::true_type{});
+    }
+    for (; t < c.nk; t += 2) {
+      step(t, I0{}, std::false_type{});
+      if (t + 1 < c.nk) step(t + 1, I1{}, std::false_type{});
+    }
+  } else {
 #pragma unroll
   for (int t = 0; t < S::DEPTH; ++t) gp_issue_tile<BM, DEEP>(c, t);
 
@@ -157,6 +251,7 @@ __global__ __launch_bounds__(512) void gemm_panel_kernel(const bf16_t* __restric
     __builtin_amdgcn_s_setprio(0);
     // every LDS read of this K-tile has been consumed by an MFMA above, so passing the next
     // barrier implies this wave is done with the stage
+  }
   }
 
   const int nbase = blockIdx.x * GP_BN + wn * (S::NT_W * 16), mbase = wm * (S::MT_W * 16);
@@ -250,8 +345,8 @@ __global__ __launch_bounds__(512) void gemm_panel_grouped_kernel(const bf16_t* _
     char* stage = smem + (t % S::NSTAGE) * S::STAGE;
     const bf16_t* src = Wp + (static_cast<size_t>(nt0 + wave) * KT + t * 2) * 512 + lane * 8;
     char* dst = stage + (wave * 2) * 1024;
-    __builtin_amdgcn_global_load_lds(LC_GLOBAL_PTR(src), LC_LDS_PTR(dst), 16, 0, 0);
-    __builtin_amdgcn_global_load_lds(LC_GLOBAL_PTR(src + 512), LC_LDS_PTR(dst + 1024), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds(LC_GLOBAL_PTR(src), LC_LDS_PTR(dst), 16, 0, GP_NT);
+    __builtin_amdgcn_global_load_lds(LC_GLOBAL_PTR(src + 512), LC_LDS_PTR(dst + 1024), 16, 0, GP_NT);
 #pragma unroll
     for (int q = 0; q < S::XP; ++q) {
       const int piece = (q * 8 + wave) % (BM / 8);
