@@ -51,6 +51,7 @@ def parse_args():
     ap.add_argument("--sc-questions", type=int, default=16, help="questions per GPU per step (workload B)")
     ap.add_argument("--sc-steps", type=int, default=None, help="timed steps of workload B (default: --steps)")
     ap.add_argument("--skip-self-consistency", action="store_true")
+    ap.add_argument("--skip-stream", action="store_true", help="skip the standing-queue runs of workload A")
     ap.add_argument("--proto-questions", type=int, default=8,
                     help="questions per GPU per step of the reference-protocol workload (0 = skip)")
     ap.add_argument("--proto-prompt-len", type=int, default=128)
@@ -181,6 +182,36 @@ def main() -> None:
         },
         "init_s": round(init_s, 1),
     }
+    if not a.skip_stream:
+        # The same ensemble under a standing queue: the questions of all timed steps are submitted
+        # together instead of one step's worth at a time, first with prefill-only / decode-only
+        # steps, then with mixed steps (decoding chains ride along in the steps that prefill later
+        # prompts, so one pass over the weights serves both).
+        def run_stream(n_total):
+            comm.barrier()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            res = vote.ask_many(make_questions(rng, n_total, a.prompt_len))
+            n = int(gather_answers(res).numel())
+            torch.cuda.synchronize()
+            comm.barrier()
+            return comm.max_float(time.perf_counter() - t0), n, [r.latency_s * 1e3 for r in res]
+
+        out["standing_queue"] = {"questions_in_flight_per_gpu": a.questions * a.steps}
+        for mix in (False, True):
+            for m in members:
+                m.backend.engine.sched.set_mix_decode(mix)
+            run_stream(a.questions * max(1, a.warmup))
+            el_s, n_s, lat_s = run_stream(a.questions * a.steps)
+            st = members[0].backend.stats()
+            out["standing_queue"]["mixed_steps" if mix else "separate_steps"] = {
+                "value": round(n_s / el_s, 3), "unit": "answers/s",
+                "ms_per_64_questions": round(el_s / a.steps * 1e3, 2),
+                "p50_latency_ms": round(float(np.percentile(comm.gather_floats(lat_s), 50)), 1),
+            }
+        out["standing_queue"]["rider_tokens_first_member"] = int(st.get("prefill.rider_tokens", 0))
+        for m in members:
+            m.backend.engine.sched.set_mix_decode(False)
     if not a.skip_self_consistency:
         steps_b = a.sc_steps or a.steps
         st_before = members[0].backend.stats()

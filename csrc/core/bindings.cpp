@@ -250,6 +250,7 @@ PYBIND11_MODULE(_core, m) {
       .def(py::init<>())
       .def_readwrite("max_batch_seqs", &SchedulerConfig::max_batch_seqs)
       .def_readwrite("max_prefill_tokens", &SchedulerConfig::max_prefill_tokens)
+      .def_readwrite("mix_decode", &SchedulerConfig::mix_decode)
       .def_readwrite("max_blocks_per_seq", &SchedulerConfig::max_blocks_per_seq);
   py::class_<ChainOutput>(m, "ChainOutput")
       .def_readonly("tokens", &ChainOutput::tokens)
@@ -291,6 +292,7 @@ PYBIND11_MODULE(_core, m) {
       .def_property_readonly("cu_q", [](const StepPlan& p) { return to_array(p.cu_q); })
       .def_property_readonly("last_rows", [](const StepPlan& p) { return to_array(p.last_rows); })
       .def_property_readonly("last_row_seq", [](const StepPlan& p) { return to_array(p.last_row_seq); })
+      .def_readonly("rider_first", &StepPlan::rider_first)
       .def_property_readonly("group_first", [](const StepPlan& p) { return to_array(p.group_first); })
       .def_property_readonly("group_count", [](const StepPlan& p) { return to_array(p.group_count); })
       .def_property_readonly("group_shared_blocks",
@@ -310,6 +312,8 @@ PYBIND11_MODULE(_core, m) {
            py::arg("params") = SamplingParams{})
       .def("abort_request", &Scheduler::abort_request)
       .def("schedule", &Scheduler::schedule)
+      .def("set_mix_decode", &Scheduler::set_mix_decode)
+      .def_property_readonly("mix_decode", &Scheduler::mix_decode)
       .def("prefill_sample_layout", &Scheduler::prefill_sample_layout)
       .def("complete_prefill",
            [](Scheduler& s, const StepPlan& plan, i32arr toks, f32arr lps) {

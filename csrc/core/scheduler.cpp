@@ -137,6 +137,38 @@ StepPlan Scheduler::schedule() {
       }
       budget -= take;
     }
+    if (cfg_.mix_decode && !plan.seq_ids.empty()) {
+      const int first = static_cast<int>(plan.seq_ids.size());
+      for (int gid : running_) {
+        Group& g = groups_.at(gid);
+        for (size_t k = 0; k < g.chains.size(); ++k) {
+          Chain& c = g.chains[k];
+          if (c.done) continue;
+          if (!kv_->reserve(c.seq, 1))
+            throw std::runtime_error("Scheduler: KV pool exhausted despite admission budget");
+          const int pos = kv_->num_tokens(c.seq);
+          const auto& bt = kv_->block_table(c.seq);
+          const int row = static_cast<int>(plan.token_ids.size());
+          plan.token_ids.push_back(c.last_token);
+          plan.positions.push_back(pos);
+          plan.slot_mapping.push_back(bt[pos / bs] * bs + pos % bs);
+          plan.seq_ids.push_back(c.seq);
+          plan.request_ids.push_back(gid);
+          plan.context_lens.push_back(pos + 1);
+          plan.cu_q.push_back(row + 1);
+          plan.step_index.push_back(static_cast<int32_t>(c.out.size()));
+          plan.seeds.push_back(g.p.seed + k);
+        }
+      }
+      if (static_cast<int>(plan.seq_ids.size()) > first) {
+        plan.rider_first = first;
+        auto copies = kv_->take_pending_copies();
+        for (auto& c : copies) {
+          plan.copy_src.push_back(c.first);
+          plan.copy_dst.push_back(c.second);
+        }
+      }
+    }
     pack_block_tables(plan, *kv_);
     return plan;
   }
@@ -254,7 +286,8 @@ void Scheduler::complete_prefill(const StepPlan& plan, const int32_t* first_toke
   int cursor = 0;  // into first_tokens, in prefill_sample_layout order
   std::vector<int> completed;
   size_t last_j = 0;
-  for (size_t i = 0; i < plan.seq_ids.size(); ++i) {
+  const size_t n_prefill = plan.rider_first >= 0 ? static_cast<size_t>(plan.rider_first) : plan.seq_ids.size();
+  for (size_t i = 0; i < n_prefill; ++i) {
     const int gid = plan.request_ids[i];
     Group& g = groups_.at(gid);
     const int take = plan.cu_q[i + 1] - plan.cu_q[i];
@@ -284,6 +317,30 @@ void Scheduler::complete_prefill(const StepPlan& plan, const int32_t* first_toke
       else if (static_cast<int>(c.out.size()) >= g.p.max_new_tokens) finish_chain(g, c, FinishReason::Length);
     }
   }
+  // Riders: their sampled tokens follow those of the completed prompts, in plan order. Handled
+  // before the newly prefilled groups join running_, exactly as a decode step would.
+  std::vector<int> touched;
+  for (size_t i = n_prefill; i < plan.seq_ids.size(); ++i) {
+    const int gid = plan.request_ids[i];
+    Group& g = groups_.at(gid);
+    Chain* chain = nullptr;
+    for (auto& c : g.chains)
+      if (!c.done && c.seq == plan.seq_ids[i]) chain = &c;
+    if (!chain) throw std::logic_error("complete_prefill: rider does not match scheduler state");
+    if (cursor >= n) throw std::invalid_argument("complete_prefill: too few sampled tokens");
+    Chain& c = *chain;
+    kv_->commit(c.seq, &c.last_token, 1);
+    const int32_t tok = first_tokens[cursor];
+    c.cum_logprob += first_logprobs ? first_logprobs[cursor] : 0.0;
+    ++cursor;
+    c.out.push_back(tok);
+    c.last_token = tok;
+    FinishReason why;
+    if (is_stop(g, tok, &why)) finish_chain(g, c, why);
+    else if (static_cast<int>(c.out.size()) >= g.p.max_new_tokens) finish_chain(g, c, FinishReason::Length);
+    if (touched.empty() || touched.back() != gid) touched.push_back(gid);
+  }
+  for (int gid : touched) maybe_retire(gid);
   for (int gid : completed) {
     prefilling_.erase(std::remove(prefilling_.begin(), prefilling_.end(), gid), prefilling_.end());
     running_.push_back(gid);

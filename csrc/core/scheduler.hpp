@@ -39,6 +39,11 @@ struct SchedulerConfig {
   int max_batch_seqs = 256;        // decode batch ceiling
   int max_prefill_tokens = 8192;   // token budget of one prefill step
   int max_blocks_per_seq = 0;      // 0 => derived from the longest admitted request
+  // Mixed steps: while prompts are being prefilled, the chains that are already decoding ride
+  // along in the same step as one-token sequences, so the step's GEMMs stream the weights once
+  // for both and a steady flow of requests never alternates between prefill-only and
+  // decode-only steps.
+  bool mix_decode = false;
 };
 
 enum class FinishReason : uint8_t { Length = 0, Eos = 1, Stop = 2, PrefillOnly = 3, Aborted = 4 };
@@ -75,6 +80,9 @@ struct StepPlan {
   std::vector<int32_t> cu_q;           // [B+1] prefix sums of chunk lengths
   std::vector<int32_t> last_rows;      // rows in [0,T) whose logits/hidden are needed (prompt ends here)
   std::vector<int32_t> last_row_seq;   // [len(last_rows)] index into seq_ids
+  // Mixed steps: sequences [rider_first, B) are decoding chains (one token each, their rows are
+  // the last ones of the step); step_index / seeds below hold one entry per rider. -1 = none.
+  int rider_first = -1;
 
   // ---- decode ----
   // positions[b] = index of the token being fed; slot_mapping[b] where its KV goes.
@@ -99,6 +107,8 @@ class Scheduler {
   void abort_request(int request_id);
 
   StepPlan schedule();
+  void set_mix_decode(bool on) { cfg_.mix_decode = on; }
+  bool mix_decode() const { return cfg_.mix_decode; }
 
   // Prefill bookkeeping: marks the plan's chunks as computed. For groups whose
   // prompt completed, `first_tokens`/`first_logprobs` hold one sampled token per

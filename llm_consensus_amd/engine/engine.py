@@ -345,7 +345,7 @@ class Engine:
                  max_batch_seqs: int = 256, max_prefill_tokens: int = 8192, max_model_len: int = 4096,
                  kv_fraction: float = 0.6, enable_prefix_cache: bool = True, use_graphs: Optional[bool] = None,
                  graph_buckets: Sequence[int] = (1, 2, 4, 8, 16, 32, 64, 128, 256), max_decision: int = 8,
-                 max_group_rows: int = 16, name: str = "engine") -> None:
+                 max_group_rows: int = 16, name: str = "engine", mix_decode: bool = False) -> None:
         self.model, self.device, self.name = model, model.device, name
         cfg = model.cfg
         self.block_size = block_size
@@ -361,6 +361,10 @@ class Engine:
         self.kvm = core.KVManager(num_kv_blocks, block_size, enable_prefix_cache)
         sc = core.SchedulerConfig()
         sc.max_batch_seqs, sc.max_prefill_tokens = max_batch_seqs, max_prefill_tokens
+        # Mixed steps: chains that are already decoding ride along in the steps that prefill newly
+        # arrived prompts (one pass over the weights serves both). Meant for a steady flow of
+        # requests; a single batch that arrives together gains nothing from it.
+        sc.mix_decode = mix_decode
         self.sched = core.Scheduler(self.kvm, sc)
         self.max_batch_seqs = max_batch_seqs
         self.max_blocks_cap = (self.max_model_len + block_size - 1) // block_size + 1
@@ -521,13 +525,26 @@ class Engine:
     def _prefill_launch(self, plan):
         m = self.model
         tok = self._dev(plan.token_ids)
-        meta = AttnMeta(is_prefill=True, block_tables=self._dev(plan.block_tables), ctx_lens=self._dev(plan.context_lens),
-                        cu_q=self._dev(plan.cu_q), max_q_len=int(np.diff(plan.cu_q).max()))
+        rf = plan.rider_first
+        n_seq = len(plan.seq_ids)
+        n_riders = n_seq - rf if rf >= 0 else 0
+        cu = plan.cu_q
+        if n_riders:
+            # Mixed step: sequences [rf, n_seq) are decoding chains with one token each.
+            bt, ctx = self._dev(plan.block_tables), self._dev(plan.context_lens)
+            riders = AttnMeta(is_prefill=False, block_tables=bt[rf:], ctx_lens=ctx[rf:],
+                              nsplit=ops.choose_kv_splits(n_riders, m.hkv, int(plan.context_lens[rf:].max()))
+                              if self.device.type == "cuda" else 1)
+            meta = AttnMeta(is_prefill=True, block_tables=bt[:rf], ctx_lens=ctx[:rf], cu_q=self._dev(cu[:rf + 1]),
+                            max_q_len=int(np.diff(cu[:rf + 1]).max()), riders=riders, prefill_tokens=int(cu[rf]))
+            self.metrics.inc("prefill.rider_tokens", n_riders)
+        else:
+            meta = AttnMeta(is_prefill=True, block_tables=self._dev(plan.block_tables),
+                            ctx_lens=self._dev(plan.context_lens), cu_q=self._dev(cu), max_q_len=int(np.diff(cu).max()))
         hidden = m.forward(tok, self._dev(plan.positions), self._dev(plan.slot_mapping), meta, self.kv)
         req_ids = plan.request_ids
         # Embed requests: accumulate the sum of this chunk's final hidden states.
-        cu = plan.cu_q
-        for i, rid in enumerate(req_ids):
+        for i, rid in enumerate(req_ids[:n_seq - n_riders]):
             st = self._reqs[int(rid)]
             if st.kind == core.RequestKind.Embed:
                 rows = hidden[int(cu[i]):int(cu[i + 1])].float()
@@ -535,19 +552,36 @@ class Engine:
                 st.embed_sum = s if st.embed_sum is None else st.embed_sum + s
                 st.embed_count += rows.shape[0]
         toks = lps = logits = None
-        if len(plan.last_rows):
-            rows = hidden[self._dev(plan.last_rows, torch.int64)]
+        n_last = len(plan.last_rows)
+        if n_last or n_riders:
+            # logits rows: the prompts that end in this step, then the riders (the step's last rows)
+            need = np.concatenate([plan.last_rows, cu[rf:n_seq]]) if n_riders else plan.last_rows
+            rows = hidden[self._dev(need, torch.int64)]
             logits = m.logits(rows)
             slots = self.sched.prefill_sample_layout(plan)
-            if slots:
-                ri = self._dev(np.array([s.last_row_index for s in slots], dtype=np.int32))
+            if slots or n_riders:
+                ri = [s.last_row_index for s in slots] + list(range(n_last, n_last + n_riders))
+                temp, top_p, top_k = ([getattr(s, f) for s in slots] for f in ("temperature", "top_p", "top_k"))
+                seeds = [s.seed for s in slots]
+                steps = [0] * len(slots)
+                if n_riders:
+                    cache: Dict[int, tuple] = {}
+                    for rid in req_ids[rf:]:
+                        e = cache.get(int(rid))
+                        if e is None:
+                            p = self.sched.params_of(int(rid))
+                            e = cache[int(rid)] = (p.temperature, p.top_p, p.top_k)
+                        temp.append(e[0]); top_p.append(e[1]); top_k.append(e[2])
+                    seeds += [int(x) for x in plan.seeds]
+                    steps += [int(x) for x in plan.step_index]
                 toks, lps = ops.sample(
                     logits,
-                    self._dev(np.array([s.temperature for s in slots], dtype=np.float32), torch.float32),
-                    self._dev(np.array([s.top_p for s in slots], dtype=np.float32), torch.float32),
-                    self._dev(np.array([s.top_k for s in slots], dtype=np.int32)),
-                    self._dev(np.array([s.seed for s in slots], dtype=np.int64), torch.int64),
-                    self._dev(np.zeros(len(slots), dtype=np.int32)), ri)
+                    self._dev(np.array(temp, dtype=np.float32), torch.float32),
+                    self._dev(np.array(top_p, dtype=np.float32), torch.float32),
+                    self._dev(np.array(top_k, dtype=np.int32)),
+                    self._dev(np.array(seeds, dtype=np.uint64).astype(np.int64), torch.int64),
+                    self._dev(np.array(steps, dtype=np.int32)),
+                    self._dev(np.array(ri, dtype=np.int32)))
         return toks, lps, logits
 
     def _prefill_finish(self, plan, state) -> None:
@@ -581,6 +615,23 @@ class Engine:
                     else:
                         for k in range(st.n):
                             st.decisions[st.seed + k] = v
+            rf = plan.rider_first
+            if rf >= 0:
+                # Riders with decision targets: same bookkeeping as a decode step (the newest row
+                # block is kept, rows are resolved when their chain leaves the batch).
+                r_req = np.array(req_ids[rf:], copy=True)
+                dec = [self._reqs[int(r)].decision_ids for r in r_req]
+                if any(dec):
+                    ids_h = np.zeros((len(dec), self.max_decision), dtype=np.int32)
+                    for i, d in enumerate(dec):
+                        if d:
+                            ids_h[i, : len(d)] = d
+                    n_last = len(plan.last_rows)
+                    rows = self._dev(np.arange(n_last, n_last + len(dec), dtype=np.int32))
+                    vals = ops.logprob_gather(logits, self._dev(ids_h), rows).cpu().numpy()
+                    cur = (r_req, np.array(plan.seeds, copy=True), vals)
+                    self._flush_decisions(keep=cur)
+                    self._last_dec = cur
         self.sched.complete_prefill(plan, first_tokens.astype(np.int32), first_lps.astype(np.float32))
 
     def _bucket(self, B: int) -> int:
@@ -647,18 +698,21 @@ class Engine:
         put("seeds", plan.seeds.astype(np.int64))
         put("steps", plan.step_index)
         if with_prefix:
-            ng = len(gcount)
-            if ng > g.gmax:
+            # Only groups of several rows with common blocks run the prefix pass (the per-row pass
+            # skips the prefix for exactly those rows: kv_begin > 0 below). There are at most B / 2
+            # of them, which is what the graph's group slots are sized for; single-row groups are
+            # left out.
+            sel = np.nonzero((gshared > 0) & (gcount > 1))[0]
+            if len(sel) > g.gmax:
                 raise RuntimeError("more sequence groups than the decode graph was sized for")
-            put("group_first", plan.group_first)
-            # only groups the per-row pass skips the prefix for (kv_begin > 0 below) may run the prefix pass
-            put("group_count", np.where((gshared > 0) & (gcount > 1), gcount, 0).astype(np.int32))
-            put("group_shared", gshared)
+            gfirst = np.asarray(plan.group_first)
+            put("group_first", gfirst[sel])
+            put("group_count", gcount[sel].astype(np.int32))
+            put("group_shared", gshared[sel])
             kvb = np.zeros(B, np.int32)
-            for gi in range(ng):
-                if gshared[gi] > 0 and gcount[gi] > 1:
-                    f, c = int(plan.group_first[gi]), int(gcount[gi])
-                    kvb[f:f + c] = int(gshared[gi]) * self.block_size
+            for gi in sel:
+                f, c = int(gfirst[gi]), int(gcount[gi])
+                kvb[f:f + c] = int(gshared[gi]) * self.block_size
             put("kv_begin", kvb)
         g.upload()
         t_launch = time.perf_counter()

@@ -38,6 +38,10 @@ class AttnMeta:
     kv_begin: Optional[torch.Tensor] = None    # [B] first private key of each row (decode, with groups)
     max_group_rows: int = 0
     prefix_splits: int = 1
+    # Mixed step: the first ``prefill_tokens`` rows belong to the prefill sequences described
+    # above; the remaining rows are one-token decode sequences described by ``riders``.
+    riders: Optional["AttnMeta"] = None
+    prefill_tokens: int = 0
 
 
 @dataclass
@@ -218,7 +222,16 @@ class TransformerModel:
             kc, vc = kv.k(i), kv.vt(i)
             qkv = ops.rope_kv_write(qkv, positions, slot_mapping, self.cos_t, self.sin_t, kc, vc, self.hq, self.hkv,
                                     c.head_dim)
-            if meta.is_prefill:
+            if meta.is_prefill and meta.riders is not None:
+                # Prompt chunks through the prefill kernel, the decoding rows behind them through
+                # the decode kernel (which reads each KV head once for all of its query heads).
+                Tp, r = meta.prefill_tokens, meta.riders
+                a = torch.empty(qkv.shape[0], self.hq * c.head_dim, dtype=qkv.dtype, device=qkv.device)
+                ops.attn_prefill(qkv[:Tp], kc, vc, meta.block_tables, meta.cu_q, meta.ctx_lens, meta.max_q_len,
+                                 self.hq, self.hkv, c.head_dim, self.scale, c.sliding_window, out=a[:Tp])
+                ops.attn_decode(qkv[Tp:], kc, vc, r.block_tables, r.ctx_lens, self.hq, self.hkv, c.head_dim,
+                                self.scale, c.sliding_window, r.nsplit, out=a[Tp:])
+            elif meta.is_prefill:
                 a = ops.attn_prefill(qkv, kc, vc, meta.block_tables, meta.cu_q, meta.ctx_lens, meta.max_q_len,
                                      self.hq, self.hkv, c.head_dim, self.scale, c.sliding_window)
             else:

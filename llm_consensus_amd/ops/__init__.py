@@ -377,14 +377,17 @@ def copy_blocks(kv_base: torch.Tensor, src: torch.Tensor, dst: torch.Tensor, blo
 
 # ---------------------------------------------------------------------------- attention
 def attn_prefill(qkv, k_cache, vt_cache, block_tables, cu_q, ctx_lens, max_q_len, Hq, Hkv, Dh, scale,
-                 window: int = 0) -> torch.Tensor:
-    """qkv [T, (Hq+2Hkv)*Dh] after rope_kv_write; returns [T, Hq*Dh]."""
+                 window: int = 0, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """qkv [T, (Hq+2Hkv)*Dh] after rope_kv_write; returns [T, Hq*Dh] (written into ``out``, a
+    contiguous row range of a larger tensor, when given)."""
     T = qkv.shape[0]
     if not qkv.is_cuda:
-        return ref.attn_prefill(qkv[:, : Hq * Dh], k_cache, vt_cache, block_tables, cu_q, ctx_lens, Hq, Hkv, Dh,
-                                scale, window)
+        r = ref.attn_prefill(qkv[:, : Hq * Dh], k_cache, vt_cache, block_tables, cu_q, ctx_lens, Hq, Hkv, Dh,
+                             scale, window)
+        return r if out is None else out.copy_(r)
     h = _hip()
-    out = torch.empty(T, Hq * Dh, dtype=qkv.dtype, device=qkv.device)
+    if out is None:
+        out = torch.empty(T, Hq * Dh, dtype=qkv.dtype, device=qkv.device)
     h.call("lc_attn_prefill", qkv.data_ptr(), qkv.stride(0), k_cache.data_ptr(), vt_cache.data_ptr(),
            block_tables.data_ptr(), block_tables.shape[1], cu_q.data_ptr(), ctx_lens.data_ptr(), out.data_ptr(),
            ctx_lens.numel(), int(max_q_len), Hq, Hkv, Dh, k_cache.shape[2], float(scale), int(window))
@@ -412,17 +415,19 @@ def choose_kv_splits(B: int, Hkv: int, max_ctx: int) -> int:
 def attn_decode(qkv, k_cache, vt_cache, block_tables, ctx_lens, Hq, Hkv, Dh, scale, window: int = 0,
                 nsplit: int = 1, groups: Optional[Tuple[torch.Tensor, torch.Tensor, torch.Tensor]] = None,
                 kv_begin: Optional[torch.Tensor] = None, max_group_rows: int = 0,
-                prefix_splits: int = 1) -> torch.Tensor:
+                prefix_splits: int = 1, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """One query token per row of qkv [B, (Hq+2Hkv)*Dh]. ``groups`` = (first, count,
     shared_blocks) int32 device tensors enables the shared-prefix pass: rows of a group
     attend to their common leading blocks in one MFMA pass and ``kv_begin`` [B] tells the
     per-row pass where each row's private suffix starts."""
     B = qkv.shape[0]
     if not qkv.is_cuda:
-        return ref.attn_decode(qkv[:, : Hq * Dh], k_cache, vt_cache, block_tables, ctx_lens, Hq, Hkv, Dh, scale,
-                               window)
+        r = ref.attn_decode(qkv[:, : Hq * Dh], k_cache, vt_cache, block_tables, ctx_lens, Hq, Hkv, Dh, scale,
+                            window)
+        return r if out is None else out.copy_(r)
     h = _hip()
-    out = torch.empty(B, Hq * Dh, dtype=qkv.dtype, device=qkv.device)
+    if out is None:
+        out = torch.empty(B, Hq * Dh, dtype=qkv.dtype, device=qkv.device)
     use_prefix = groups is not None and max_group_rows > 1
     # Up to four of the requested KV splits are taken by the waves of one workgroup, which
     # merges them on chip; only the remaining factor produces partial slots in HBM.

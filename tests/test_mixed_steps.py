@@ -1,0 +1,94 @@
+"""Mixed steps: while new prompts are prefilled, the chains that are already decoding ride along
+in the same step as one-token sequences. Results must not depend on how steps were composed."""
+import numpy as np
+import pytest
+
+from llm_consensus_amd._native import core
+from llm_consensus_amd.engine.engine import Engine
+from llm_consensus_amd.models.config import get_preset
+from llm_consensus_amd.models.transformer import TransformerModel
+
+
+def toks(n, start=0):
+    return np.arange(start, start + n, dtype=np.int32)
+
+
+def test_scheduler_appends_running_chains_to_a_prefill_plan():
+    kv = core.KVManager(256, 4, False)
+    cfg = core.SchedulerConfig()
+    cfg.max_batch_seqs, cfg.max_prefill_tokens, cfg.mix_decode = 16, 64, True
+    sched = core.Scheduler(kv, cfg)
+    p = core.SamplingParams(); p.max_new_tokens = 3; p.seed = 40
+    a = sched.add_request(core.RequestKind.Generate, toks(10), 2, p)
+    plan = sched.schedule()
+    assert plan.kind == core.StepPlan.Kind.Prefill and plan.rider_first == -1
+    sched.complete_prefill(plan, np.array([7, 8], np.int32), np.zeros(2, np.float32))
+    b = sched.add_request(core.RequestKind.Generate, toks(6, 100), 1, p)
+    plan = sched.schedule()                       # b's prompt + a's two chains as riders
+    assert plan.kind == core.StepPlan.Kind.Prefill and plan.rider_first == 1
+    assert np.diff(plan.cu_q).tolist() == [6, 1, 1]
+    assert plan.token_ids[-2:].tolist() == [7, 8] and plan.positions[-2:].tolist() == [10, 10]
+    assert plan.context_lens.tolist() == [6, 11, 11]
+    assert plan.seeds.tolist() == [40, 41] and plan.step_index.tolist() == [1, 1]
+    assert len(sched.prefill_sample_layout(plan)) == 1
+    # sampled tokens: b's first token, then one per rider
+    sched.complete_prefill(plan, np.array([5, 9, 10], np.int32), np.zeros(3, np.float32))
+    plan = sched.schedule()                       # nothing left to prefill: a plain decode step
+    assert plan.kind == core.StepPlan.Kind.Decode and plan.token_ids.tolist() == [9, 10, 5]
+    sched.complete_decode(plan, np.array([1, 2, 3], np.int32), np.zeros(3, np.float32))
+    fin = {f.request_id: f for f in sched.take_finished()}
+    assert [list(c.tokens) for c in fin[a].chains] == [[7, 9, 1], [8, 10, 2]]
+    while sched.has_work():
+        pl = sched.schedule()
+        sched.complete_decode(pl, np.ones(len(pl.seq_ids), np.int32), np.zeros(len(pl.seq_ids), np.float32))
+    fin = {f.request_id: f for f in sched.take_finished()}
+    assert list(fin[b].chains[0].tokens) == [5, 3, 1] and kv.available_blocks() == 256
+
+
+def _staggered_run(model, mix, device_graphs=False):
+    eng = Engine(model, num_kv_blocks=256, block_size=16, use_graphs=device_graphs, mix_decode=mix,
+                 max_prefill_tokens=64)
+    sp = core.SamplingParams(); sp.max_new_tokens = 9; sp.temperature = 0.0
+    dec = [3, 9]
+    rids = []
+    waves = [[list(range(5 + 3 * i, 45 + 4 * i)) for i in range(2)],
+             [list(range(100 + i, 130 + 5 * i)) for i in range(3)],
+             [list(range(200, 290))]]                       # longer than one step's token budget
+    for w, wave in enumerate(waves):
+        for j, pr in enumerate(wave):
+            sp.seed = 10 * w + j
+            rids.append(eng.submit(pr, n=2 if j == 0 else 1, params=sp, decision_ids=dec))
+        for _ in range(3):                                  # a few steps, then the next wave arrives
+            eng.step()
+    eng.run_until_done()
+    return [eng.pop_result(r) for r in rids], eng.stats()
+
+
+def test_engine_results_do_not_depend_on_mixing():
+    cfg = get_preset("tiny-llama")
+    model = TransformerModel.random_init(cfg, "cpu", seed=5, std=0.1)
+    plain, st_plain = _staggered_run(model, False)
+    mixed, st_mixed = _staggered_run(model, True)
+    assert st_plain.get("prefill.rider_tokens", 0) == 0 and st_mixed["prefill.rider_tokens"] > 0
+    assert st_mixed["decode.steps"] + st_mixed["prefill.steps"] <= st_plain["decode.steps"] + st_plain["prefill.steps"]
+    for a, b in zip(plain, mixed):
+        assert a.token_ids == b.token_ids and a.finish_reasons == b.finish_reasons
+        # activations are bf16: a different batch composition can flip a rounding here and there
+        assert np.allclose(a.decision_logprobs, b.decision_logprobs, atol=2e-2)
+        assert np.allclose(a.cum_logprobs, b.cum_logprobs, atol=5e-2)
+
+
+@pytest.mark.gpu
+def test_mixed_steps_on_gpu_match_plain_steps():
+    """The prompt chunks go through the prefill attention kernel and the riders behind them
+    through the decode kernel, both writing into one output tensor."""
+    cfg = get_preset("small-llama")
+    model = TransformerModel.random_init(cfg, "cuda", seed=5, std=0.05)
+    plain, _ = _staggered_run(model, False, device_graphs=True)
+    mixed, st = _staggered_run(model, True, device_graphs=True)
+    assert st["prefill.rider_tokens"] > 0
+    same = sum(a.token_ids == b.token_ids for a, b in zip(plain, mixed))
+    assert same >= len(plain) - 1          # bf16: a greedy near-tie may flip in one request
+    for a, b in zip(plain, mixed):
+        if a.token_ids == b.token_ids:
+            assert np.allclose(a.decision_logprobs, b.decision_logprobs, atol=6e-2)
