@@ -151,7 +151,9 @@ def main() -> None:
         el = comm.max_float(time.perf_counter() - t0)
         return el, n_ans, lat
 
+    st0 = [m.backend.stats() for m in members]
     el_a, n_a, lat_a = run_phase(vote, a.questions, a.steps, a.warmup)
+    st1 = [m.backend.stats() for m in members]
     lat_all = comm.gather_floats(lat_a)
     out = {
         "metric": "consensus answers/sec (node), 3x7-8B majority-vote ensemble",
@@ -181,6 +183,14 @@ def main() -> None:
             "decode": "hipGraph" if not a.no_graphs else "eager",
         },
         "init_s": round(init_s, 1),
+        # host-side view of each member engine over warmup + timed steps (the members' steps overlap on
+        # the GPU, so these wall-clock spans add up to more than the step time)
+        "member_engines": {
+            names[i]: {k: round(st1[i].get(k, 0.0) - st0[i].get(k, 0.0), 3)
+                       for k in ("prefill.steps", "prefill.seconds", "decode.steps", "decode.seconds",
+                                 "decode.wait_seconds")}
+            for i in range(len(names))
+        },
     }
     if not a.skip_stream:
         # The same ensemble under a standing queue: the questions of all timed steps are submitted

@@ -52,11 +52,23 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(bf16_t* __restrict__ h, co
       bf16x8 a = *reinterpret_cast<const bf16x8*>(hrow + c * 8);
       g[i] = *reinterpret_cast<const bf16x8*>(w + c * 8);
       if (prow) {
-        f32x4 lo = *reinterpret_cast<const f32x4*>(prow + c * 8);
-        f32x4 hi = *reinterpret_cast<const f32x4*>(prow + c * 8 + 4);
-        for (int sp = 1; sp < S; ++sp) {
-          lo += *reinterpret_cast<const f32x4*>(prow + sp * slab + c * 8);
-          hi += *reinterpret_cast<const f32x4*>(prow + sp * slab + c * 8 + 4);
+        // Eight slabs' loads at a time are issued before the first add: a loop of load-then-add
+        // pays one L2 round trip per slab, and at decode sizes this kernel is all round trips.
+        f32x4 lo = f32x4{0.f, 0.f, 0.f, 0.f}, hi = lo;
+        for (int sp0 = 0; sp0 < S; sp0 += 8) {
+          f32x4 pl[8], ph[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u)
+            if (sp0 + u < S) {
+              pl[u] = *reinterpret_cast<const f32x4*>(prow + (sp0 + u) * slab + c * 8);
+              ph[u] = *reinterpret_cast<const f32x4*>(prow + (sp0 + u) * slab + c * 8 + 4);
+            }
+#pragma unroll
+          for (int u = 0; u < 8; ++u)
+            if (sp0 + u < S) {
+              lo += pl[u];
+              hi += ph[u];
+            }
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {

@@ -37,8 +37,18 @@ __global__ __launch_bounds__(256) void rope_kv_write_kernel(
   auto load4 = [&](int col) -> f32x4 {
     f32x4 v;
     if (prow) {
-      v = *reinterpret_cast<const f32x4*>(prow + col);
-      for (int sp = 1; sp < S; ++sp) v += *reinterpret_cast<const f32x4*>(prow + sp * slab + col);
+      // All slabs' loads are issued before the first add: a loop of load-then-add would pay one
+      // L2 round trip per slab, and this kernel is nothing but round trips.
+      constexpr int MAX_S = 8;
+      f32x4 ps[MAX_S];
+#pragma unroll
+      for (int sp = 0; sp < MAX_S; ++sp)
+        if (sp < S) ps[sp] = *reinterpret_cast<const f32x4*>(prow + sp * slab + col);
+      v = ps[0];
+#pragma unroll
+      for (int sp = 1; sp < MAX_S; ++sp)
+        if (sp < S) v += ps[sp];
+      for (int sp = MAX_S; sp < S; ++sp) v += *reinterpret_cast<const f32x4*>(prow + sp * slab + col);
       if (bias) {
         const u32x2 bb = *reinterpret_cast<const u32x2*>(bias + col);
         v[0] += bf16_to_f32(static_cast<bf16_t>(bb[0] & 0xffff));
@@ -64,37 +74,39 @@ __global__ __launch_bounds__(256) void rope_kv_write_kernel(
     *reinterpret_cast<u32x2*>(dst) = o;
   };
 
-  // ---- Q and K heads: rotate pairs (i, i + HALF) ----
-  // gridDim.y blocks share a token: decode steps have few tokens, and one block per token
-  // would leave most CUs idle while every thread walks a dozen dependent load chains
+  // Work items of a token: (Hq + Hkv) * QUADS rotations (pairs (i, i + HALF) of Q and K heads) and
+  // Hkv * DH / 4 transposed V scatters, in one index space so that at decode sizes every thread
+  // has at most one item and all of a token's loads are in flight together. gridDim.y blocks
+  // share a token: decode steps have few tokens, and one block per token would leave most CUs
+  // idle while every thread walks several dependent load chains.
   const int tid = blockIdx.y * blockDim.x + threadIdx.x, nthr = gridDim.y * blockDim.x;
   const int n_rot = (Hq + Hkv) * QUADS;
-  for (int it = tid; it < n_rot; it += nthr) {
-    const int hd = it / QUADS, i = (it % QUADS) * 4;
-    if (hd >= Hq && slot < 0) continue;
-    const f32x4 a = load4(hd * DH + i), b = load4(hd * DH + i + HALF);
-    const f32x4 c = *reinterpret_cast<const f32x4*>(cos_t + static_cast<size_t>(pos) * HALF + i);
-    const f32x4 sn = *reinterpret_cast<const f32x4*>(sin_t + static_cast<size_t>(pos) * HALF + i);
-    f32x4 ra, rb;
+  const int n_v = slot < 0 ? 0 : Hkv * (DH / 4);
+  for (int it = tid; it < n_rot + n_v; it += nthr) {
+    if (it < n_rot) {
+      const int hd = it / QUADS, i = (it % QUADS) * 4;
+      if (hd >= Hq && slot < 0) continue;
+      const f32x4 a = load4(hd * DH + i), b = load4(hd * DH + i + HALF);
+      const f32x4 c = *reinterpret_cast<const f32x4*>(cos_t + static_cast<size_t>(pos) * HALF + i);
+      const f32x4 sn = *reinterpret_cast<const f32x4*>(sin_t + static_cast<size_t>(pos) * HALF + i);
+      f32x4 ra, rb;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      ra[j] = a[j] * c[j] - b[j] * sn[j];
-      rb[j] = b[j] * c[j] + a[j] * sn[j];
+      for (int j = 0; j < 4; ++j) {
+        ra[j] = a[j] * c[j] - b[j] * sn[j];
+        rb[j] = b[j] * c[j] + a[j] * sn[j];
+      }
+      bf16_t* dst = hd < Hq ? row + hd * DH
+                            : Kc + ((static_cast<size_t>(blk) * Hkv + (hd - Hq)) * BS + off) * DH;
+      store4(dst + i, ra);
+      store4(dst + i + HALF, rb);
+    } else {
+      const int iv = it - n_rot;
+      const int vh = iv / (DH / 4), i = (iv % (DH / 4)) * 4;
+      const f32x4 v = load4((Hq + Hkv + vh) * DH + i);
+      bf16_t* dst = Vt + ((static_cast<size_t>(blk) * Hkv + vh) * DH + i) * BS + off;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) dst[static_cast<size_t>(j) * BS] = f32_to_bf16(v[j]);
     }
-    bf16_t* dst = hd < Hq ? row + hd * DH
-                          : Kc + ((static_cast<size_t>(blk) * Hkv + (hd - Hq)) * BS + off) * DH;
-    store4(dst + i, ra);
-    store4(dst + i + HALF, rb);
-  }
-  // ---- V heads: transposed scatter ----
-  if (slot < 0) return;
-  const int n_v = Hkv * (DH / 4);
-  for (int it = tid; it < n_v; it += nthr) {
-    const int vh = it / (DH / 4), i = (it % (DH / 4)) * 4;
-    const f32x4 v = load4((Hq + Hkv + vh) * DH + i);
-    bf16_t* dst = Vt + ((static_cast<size_t>(blk) * Hkv + vh) * DH + i) * BS + off;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) dst[static_cast<size_t>(j) * BS] = f32_to_bf16(v[j]);
   }
 }
 
