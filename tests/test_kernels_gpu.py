@@ -231,6 +231,42 @@ def test_rope_kv_write_matches_reference(Hq, Hkv, Dh, BS):
     assert rel_err(kg, kc) < 4e-3 and torch.equal(vg.cpu(), vc)
 
 
+@pytest.mark.parametrize("Hq,Hkv,Dh,BS", [(8, 2, 128, 64), (14, 2, 64, 16), (4, 1, 128, 8)])
+def test_rope_kv_write_prefill_sized_step(Hq, Hkv, Dh, BS):
+    """More than 512 tokens: V goes through the LDS-transposing kernel. The slot list mixes whole
+    aligned runs (a prompt filling blocks in order), a prompt that starts mid-run, scattered slots,
+    skipped tokens and a ragged end."""
+    T = 1000
+    nblocks = max((3 * T) // BS + 4, 220)
+    perm = torch.randperm(nblocks, generator=torch.Generator().manual_seed(5))
+    slots = torch.full((T,), -1, dtype=torch.int32)
+    for i in range(0, 512):                      # prompt 1: consecutive slots, blocks in shuffled order
+        slots[i] = int(perm[i // BS]) * BS + i % BS
+    for i in range(512, 700):                    # prompt 2: starts 3 slots into its first block
+        j = i - 512 + 3
+        slots[i] = int(perm[100 + j // BS]) * BS + j % BS
+    n_sc = -(-250 // BS) + 1
+    scattered = torch.randperm(BS * n_sc, generator=torch.Generator().manual_seed(6))[:250]
+    base_blocks = perm[160:160 + n_sc]
+    for k, i in enumerate(range(700, 950)):      # scattered slots inside a few further blocks
+        sc = int(scattered[k])
+        slots[i] = int(base_blocks[sc // BS]) * BS + sc % BS
+    slots[5] = -1
+    slots[520] = -1                              # tokens 950.. stay -1 (padding rows)
+    assert len(set(int(x) for x in slots if x >= 0)) == int((slots >= 0).sum())
+    qkv = bf(rand(T, (Hq + 2 * Hkv) * Dh))
+    pos = torch.randint(0, 300, (T,), dtype=torch.int32)
+    cos_t, sin_t = ref.rope_tables(Dh, 512, 1e6)
+    kc, vc = make_cache(nblocks, Hkv, BS, Dh, "cpu")
+    q_ref = qkv.clone()
+    ref.rope_kv_write(q_ref, pos, slots, cos_t, sin_t, kc, vc, Hq, Hkv, Dh)
+    kg, vg = make_cache(nblocks, Hkv, BS, Dh, DEV)
+    q_gpu = qkv.to(DEV)
+    ops.rope_kv_write(q_gpu, pos.to(DEV), slots.to(DEV), cos_t.to(DEV), sin_t.to(DEV), kg, vg, Hq, Hkv, Dh)
+    assert rel_err(q_gpu[:, : Hq * Dh], q_ref[:, : Hq * Dh]) < 4e-3
+    assert rel_err(kg, kc) < 4e-3 and torch.equal(vg.cpu(), vc)
+
+
 @pytest.mark.parametrize("Hq,Hkv,Dh,BS,window", [(8, 2, 128, 64, 0), (14, 2, 64, 16, 0), (8, 1, 128, 32, 0),
                                                   (4, 4, 128, 64, 0), (8, 2, 128, 64, 40)])
 def test_attn_prefill_chunked_matches_reference(Hq, Hkv, Dh, BS, window):
