@@ -47,7 +47,14 @@ def set_concurrent_engines(n: int) -> None:
 # In-workgroup K-split decode kernel (kgemm.hip): widest output it is used for, and a test override
 # (-1 = automatic, 0 = never, 1/2/4 = force that many n-tiles per workgroup).
 KGEMM_MAX_N = int(os.environ.get("LC_KGEMM_MAX_N", "8192"))
-KGEMM_MAX_M = int(os.environ.get("LC_KGEMM_MAX_M", "16"))   # measured: beyond 16 rows the weight-streaming kernel wins
+# Most rows the in-workgroup K-split kernel is used for. Measured against the panel kernel (with
+# non-temporal weight loads) on HBM-resident weights: at 1 row it wins on the narrow projections
+# (6144x4096 10.9 vs 13.0 us, 4096x4096 7.9 vs 9.3) and ties on the wide ones; at 8 rows it still wins
+# those (11.9 vs 13.5, 8.4 vs 9.4) but loses where K is long (3584x18944: 26.5 vs 23.9); at 16 rows it
+# loses everywhere (4096x14336: 28.3 vs 21.4, 3584x18944: 36.3 vs 24.2).
+KGEMM_MAX_M = int(os.environ.get("LC_KGEMM_MAX_M", "8"))
+KGEMM_LONG_K = 8192          # beyond this K the kernel is only used up to KGEMM_LONG_K_MAX_M rows
+KGEMM_LONG_K_MAX_M = 4
 KGEMM_FORCE_NTW = int(os.environ.get("LC_KGEMM_NTW", "-1"))
 # Target number of workgroups for the weight-streaming kernel (256 CUs on MI355X).
 WS_TARGET_BLOCKS = int(os.environ.get("LC_WS_TARGET_BLOCKS", "256"))
@@ -127,13 +134,13 @@ class LinearWeight:
         return self.data.numel() * self.data.element_size() + (self.bias.numel() * 2 if self.bias is not None else 0)
 
 
-def _kgemm_ntw(n_pad: int, M: int, swiglu: bool) -> int:
+def _kgemm_ntw(n_pad: int, M: int, swiglu: bool, K: int = 0) -> int:
     """n-tiles per workgroup for the in-workgroup K-split kernel, or 0 to use another kernel.
     It re-reads the activations once per workgroup from L2, so it is limited to M <= 64 and
     to outputs narrow enough that this stays below the weight traffic."""
     if KGEMM_FORCE_NTW >= 0:
         return KGEMM_FORCE_NTW if M <= 64 else 0
-    if M > KGEMM_MAX_M or n_pad > KGEMM_MAX_N:
+    if M > KGEMM_MAX_M or n_pad > KGEMM_MAX_N or (K > KGEMM_LONG_K and M > KGEMM_LONG_K_MAX_M):
         return 0
     for ntw in (4, 2, 1):
         if swiglu and ntw < 2:
@@ -253,7 +260,7 @@ def linear(x: torch.Tensor, w: LinearWeight, out_f32: bool = False, defer_reduce
                out_n, epi)
         return y
     # ---- decode shapes: one activation panel of at most 256 rows ----
-    ntw = _kgemm_ntw(w.n_pad, M, w.swiglu)
+    ntw = _kgemm_ntw(w.n_pad, M, w.swiglu, w.k)
     if ntw:   # a handful of rows, narrow output: K split over the waves of one workgroup
         h.call("lc_kgemm", w.data.data_ptr(), x.data_ptr(), y.data_ptr(), h.ptr(w.bias), M, w.n, w.k, w.n_pad,
                out_n, epi, ntw)
