@@ -112,7 +112,7 @@ def build_backend(spec: ModelSpec, device: torch.device, comm=None, tp_rank: int
     eng = Engine(model, block_size=spec.kv_block_size if device.type == "cuda" else 16,
                  max_batch_seqs=spec.max_batch_seqs, max_prefill_tokens=spec.max_prefill_tokens,
                  max_model_len=max_len, kv_fraction=spec.kv_fraction,
-                 graph_buckets=spec.graph_batch_buckets, name=spec.name,
+                 graph_buckets=spec.graph_batch_buckets, name=spec.name, mix_decode=spec.mix_decode,
                  num_kv_blocks=None if device.type == "cuda" else 512)
     tok = make_tokenizer(spec.tokenizer, model.cfg.vocab_size)
     return EngineBackend(eng, tok, name=spec.name, stop_at_eos=spec.tokenizer is not None,

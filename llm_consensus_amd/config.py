@@ -55,6 +55,7 @@ class ModelSpec:
     kv_fraction: float = 0.6          # share of free HBM given to the KV pool
     max_batch_seqs: int = 256
     max_prefill_tokens: int = 8192
+    mix_decode: bool = False          # decoding chains ride along in the steps that prefill new prompts
     graph_batch_buckets: List[int] = field(default_factory=lambda: [1, 2, 4, 8, 16, 32, 64, 128, 256])
     tokenizer: Optional[str] = None   # HF tokenizer dir; None => byte-level fallback
     chat_format: str = "none"         # none | llama3 | chatml | mistral: turn markers around each prompt
