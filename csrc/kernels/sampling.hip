@@ -21,6 +21,7 @@ namespace {
 constexpr int kThreads = 1024;
 constexpr int kWaves = kThreads / 64;
 constexpr int kBins = 12;          // threshold-search fan-out per sweep (12 x 1024 floats of LDS)
+constexpr int kGroups = 8;         // groups per wave segment in the draw (see the draw phase)
 constexpr int kSearchPasses = 6;   // 30 / 12^6 ~ 1e-5 resolution in logit/T units
 
 struct ArgMax {
@@ -77,7 +78,7 @@ __global__ __launch_bounds__(kThreads) void sample_kernel(
   __shared__ int si[kWaves];
   __shared__ float multi[kWaves][kBins];
   extern __shared__ float hist[];  // [kBins][kThreads]
-  __shared__ float seg_sum[kWaves];
+  __shared__ float seg_sum[kWaves * kGroups];
   __shared__ float bc[2];
   __shared__ int bci[1];
   const int r = blockIdx.x;
@@ -203,27 +204,52 @@ __global__ __launch_bounds__(kThreads) void sample_kernel(
 
   // ---- draw: locate u * kept_mass in the index-ordered CDF of the kept set ----
   const float u = rng_uniform(seeds[r], static_cast<uint32_t>(steps ? steps[r] : 0), 0);
-  const int seg = ((V + kWaves - 1) / kWaves + 255) & ~255;  // elements per wave, multiple of 256
+  // Each wave owns a contiguous segment of the vocabulary, cut into kGroups groups; the sweep below
+  // leaves one mass per (wave, group), thread 0 picks the group that holds the target and only
+  // that group (1/128 of the row) is walked again, by its wave, with prefix scans.
+  const int gsz = (((V + kWaves - 1) / kWaves + kGroups - 1) / kGroups + 255) & ~255;   // multiple of 256
+  const int seg = gsz * kGroups;
   const int s0 = wid * seg, s1 = min(V, s0 + seg);
   auto kept_w = [&](int i) -> float {
     if (i >= s1) return 0.f;
     const float z = row[i] * inv_t;
     return z >= thr ? __expf(z - zmax) : 0.f;
   };
-  float mine = 0.f;
-  for (int i = s0 + lane * 4; i < s1; i += 256) mine += kept_w(i) + kept_w(i + 1) + kept_w(i + 2) + kept_w(i + 3);
-  mine = wave_sum(mine);
-  if (lane == 0) seg_sum[wid] = mine;
+  // weights of elements i .. i+3 (i is a multiple of 4): one 16-byte load when the row allows it
+  auto kept_w4 = [&](int i) -> f32x4 {
+    if (vec && i < s1) {   // V % 4 == 0 and segment bounds are multiples of 4: the quad is whole
+      const f32x4 x = *reinterpret_cast<const f32x4*>(row + i);
+      f32x4 w;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float z = x[q] * inv_t;
+        w[q] = z >= thr ? __expf(z - zmax) : 0.f;
+      }
+      return w;
+    }
+    return f32x4{kept_w(i), kept_w(i + 1), kept_w(i + 2), kept_w(i + 3)};
+  };
+#pragma unroll
+  for (int g = 0; g < kGroups; ++g) {
+    float mine = 0.f;
+    const int g1 = min(s1, s0 + (g + 1) * gsz);
+    for (int i = s0 + g * gsz + lane * 4; i < g1; i += 256) {
+      const f32x4 w4 = kept_w4(i);
+      mine += w4[0] + w4[1] + w4[2] + w4[3];
+    }
+    mine = wave_sum(mine);
+    if (lane == 0) seg_sum[wid * kGroups + g] = mine;
+  }
   __syncthreads();
   if (threadIdx.x == 0) {
     float grand = 0.f;
-    for (int w2 = 0; w2 < kWaves; ++w2) grand += seg_sum[w2];
+    for (int w2 = 0; w2 < kWaves * kGroups; ++w2) grand += seg_sum[w2];
     const float target = u * grand;
     float run = 0.f;
     int owner = 0;
-    for (int w2 = 0; w2 < kWaves; ++w2) {
+    for (int w2 = 0; w2 < kWaves * kGroups; ++w2) {
       if (seg_sum[w2] > 0.f) {
-        owner = w2;  // last non-empty segment so far: fallback when target == grand
+        owner = w2;  // last non-empty group so far: fallback when target == grand
         if (target < run + seg_sum[w2]) break;
       }
       run += seg_sum[w2];
@@ -235,13 +261,15 @@ __global__ __launch_bounds__(kThreads) void sample_kernel(
     bci[0] = owner;
   }
   __syncthreads();
-  if (wid == bci[0]) {
+  if (wid == bci[0] / kGroups) {
     const float resid = bc[0], grand = bc[1];
     float run = 0.f;
     int tok = -1, last_kept = -1;
-    for (int base = s0; base < s1 && tok < 0; base += 256) {
+    const int gb = s0 + (bci[0] % kGroups) * gsz, ge = min(s1, gb + gsz);
+    for (int base = gb; base < ge && tok < 0; base += 256) {
       const int i = base + lane * 4;
-      const float w0 = kept_w(i), w1 = kept_w(i + 1), w2 = kept_w(i + 2), w3 = kept_w(i + 3);
+      const f32x4 w4 = kept_w4(i);
+      const float w0 = w4[0], w1 = w4[1], w2 = w4[2], w3 = w4[3];
       const float mysum = w0 + w1 + w2 + w3;
       float incl = mysum;
 #pragma unroll
