@@ -100,6 +100,14 @@ StepPlan Scheduler::schedule() {
   if (!prefilling_.empty()) {
     plan.kind = StepPlan::Prefill;
     int budget = cfg_.max_prefill_tokens;
+    if (cfg_.mix_decode) {
+      // Riders count against the step's token budget: the budget is sized to whole GEMM row
+      // tiles, and a few hundred rows on top of it would start another tile row in every GEMM.
+      int riders = 0;
+      for (int gid : running_)
+        for (const auto& c : groups_.at(gid).chains) riders += c.done ? 0 : 1;
+      budget = std::max(budget - riders, budget / 2);
+    }
     plan.cu_q.push_back(0);
     for (int gid : prefilling_) {
       if (budget <= 0) break;
