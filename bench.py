@@ -57,6 +57,7 @@ def parse_args():
     ap.add_argument("--proto-prompt-len", type=int, default=128)
     ap.add_argument("--temperature", type=float, default=0.8)
     ap.add_argument("--top-p", type=float, default=0.95)
+    ap.add_argument("--prefill-tokens", type=int, default=8192, help="token budget of one prefill step")
     ap.add_argument("--no-graphs", action="store_true")
     ap.add_argument("--out", default=None, help="also write the JSON line to this file")
     return ap.parse_args()
@@ -116,7 +117,8 @@ def main() -> None:
         model = TransformerModel.random_init(cfg, dev, seed=1234 + i)
         n_blocks = (max_seqs + 8) * blocks_per_seq + 64
         eng = Engine(model, num_kv_blocks=n_blocks, block_size=bs, max_batch_seqs=max(256, max_seqs),
-                     max_prefill_tokens=8192, max_model_len=seq_len + 64, use_graphs=not a.no_graphs, name=name)
+                     max_prefill_tokens=a.prefill_tokens, max_model_len=seq_len + 64, use_graphs=not a.no_graphs,
+                     name=name)
         be = EngineBackend(eng, ByteLevelTokenizer(cfg.vocab_size), stop_at_eos=False)
         gp = GenParams(temperature=a.temperature, top_p=a.top_p, max_new_tokens=a.new_tokens, seed=17 * i)
         members.append(Member(personas[i % len(personas)], be, params=gp))
