@@ -45,6 +45,32 @@ def test_scheduler_appends_running_chains_to_a_prefill_plan():
     assert list(fin[b].chains[0].tokens) == [5, 3, 1] and kv.available_blocks() == 256
 
 
+def test_riders_count_against_the_prefill_token_budget():
+    kv = core.KVManager(512, 4, False)
+    cfg = core.SchedulerConfig()
+    cfg.max_batch_seqs, cfg.max_prefill_tokens, cfg.mix_decode = 64, 32, True
+    sched = core.Scheduler(kv, cfg)
+    p = core.SamplingParams(); p.max_new_tokens = 8
+    sched.add_request(core.RequestKind.Generate, toks(10), 6, p)         # six chains -> six riders later
+    plan = sched.schedule()
+    sched.complete_prefill(plan, np.arange(6, dtype=np.int32), np.zeros(6, np.float32))
+    sched.add_request(core.RequestKind.Generate, toks(100, 200), 1, p)   # longer than one step's budget
+    plan = sched.schedule()
+    lens = np.diff(plan.cu_q).tolist()
+    assert plan.rider_first == 1 and lens == [26] + [1] * 6 and len(plan.token_ids) == 32
+    # the budget never drops below half, however many chains are decoding
+    cfg2 = core.SchedulerConfig()
+    cfg2.max_batch_seqs, cfg2.max_prefill_tokens, cfg2.mix_decode = 64, 8, True
+    kv2 = core.KVManager(512, 4, False)
+    s2 = core.Scheduler(kv2, cfg2)
+    s2.add_request(core.RequestKind.Generate, toks(6), 7, p)
+    pl = s2.schedule()
+    s2.complete_prefill(pl, np.arange(7, dtype=np.int32), np.zeros(7, np.float32))
+    s2.add_request(core.RequestKind.Generate, toks(40, 300), 1, p)
+    pl = s2.schedule()
+    assert np.diff(pl.cu_q).tolist() == [4] + [1] * 7
+
+
 def _staggered_run(model, mix, device_graphs=False):
     eng = Engine(model, num_kv_blocks=256, block_size=16, use_graphs=device_graphs, mix_decode=mix,
                  max_prefill_tokens=64)
