@@ -221,6 +221,7 @@ PYBIND11_MODULE(_core, m) {
       .def("block_table", [](const KVManager& kv, int seq) { return kv.block_table(seq); })
       .def("shared_prefix_blocks", &KVManager::shared_prefix_blocks)
       .def("take_pending_copies", &KVManager::take_pending_copies)
+      .def("drop_cache", &KVManager::drop_cache)
       .def("available_blocks", &KVManager::available_blocks)
       .def("stats", &KVManager::stats)
       .def_property_readonly("block_size", &KVManager::block_size);
@@ -251,7 +252,11 @@ PYBIND11_MODULE(_core, m) {
       .def_readwrite("max_batch_seqs", &SchedulerConfig::max_batch_seqs)
       .def_readwrite("max_prefill_tokens", &SchedulerConfig::max_prefill_tokens)
       .def_readwrite("mix_decode", &SchedulerConfig::mix_decode)
-      .def_readwrite("max_blocks_per_seq", &SchedulerConfig::max_blocks_per_seq);
+      .def_readwrite("max_blocks_per_seq", &SchedulerConfig::max_blocks_per_seq)
+      .def_readwrite("admit_window", &SchedulerConfig::admit_window)
+      .def_readwrite("max_head_skips", &SchedulerConfig::max_head_skips)
+      .def_readwrite("optimistic_admission", &SchedulerConfig::optimistic_admission)
+      .def_readwrite("watermark_blocks", &SchedulerConfig::watermark_blocks);
   py::class_<ChainOutput>(m, "ChainOutput")
       .def_readonly("tokens", &ChainOutput::tokens)
       .def_readonly("cum_logprob", &ChainOutput::cum_logprob)
@@ -330,6 +335,8 @@ PYBIND11_MODULE(_core, m) {
       .def("has_work", &Scheduler::has_work)
       .def_property_readonly("num_waiting", &Scheduler::num_waiting)
       .def_property_readonly("num_running", &Scheduler::num_running)
+      .def_property_readonly("num_preemptions", &Scheduler::num_preemptions)
+      .def_property_readonly("num_head_skips", &Scheduler::num_head_skips)
       .def("params_of", &Scheduler::params_of, py::return_value_policy::copy)
       .def("kind_of", &Scheduler::kind_of);
 

@@ -213,7 +213,16 @@ int KVManager::fork(int seq) {
 void KVManager::free_sequence(int seq) {
   auto it = seqs_.find(seq);
   if (it == seqs_.end()) return;
-  for (int b : it->second.blocks) alloc_.decref(b);
+  for (int b : it->second.blocks) {
+    alloc_.decref(b);
+    if (alloc_.refcount(b) == 0 && !pending_copies_.empty()) {
+      // A copy-on-write into a block that nobody holds any more must not run: the block may
+      // be handed to another sequence before the queued copies execute.
+      pending_copies_.erase(std::remove_if(pending_copies_.begin(), pending_copies_.end(),
+                                           [b](const std::pair<int, int>& c) { return c.second == b; }),
+                            pending_copies_.end());
+    }
+  }
   seqs_.erase(it);
 }
 
@@ -235,6 +244,13 @@ std::vector<std::pair<int, int>> KVManager::take_pending_copies() {
   std::vector<std::pair<int, int>> out;
   out.swap(pending_copies_);
   return out;
+}
+
+void KVManager::drop_cache() {
+  for (const auto& kv : cache_) alloc_.decref(kv.second);
+  cache_.clear();
+  cached_block_hash_.clear();
+  lru_.clear();
 }
 
 int KVManager::available_blocks() const {

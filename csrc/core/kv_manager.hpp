@@ -83,6 +83,13 @@ class KVManager {
 
   std::vector<std::pair<int, int>> take_pending_copies();
 
+  // Forgets every prefix-cache entry (hash -> block) and gives back the cache's block
+  // references. Blocks still held by live sequences stay allocated; only the promise "this
+  // hash has its KV in that block" is withdrawn. Called after a failed step: blocks are
+  // registered when a step is scheduled, before the step has written them, so after a failure
+  // an entry may point at KV that was never produced.
+  void drop_cache();
+
   int block_size() const { return block_size_; }
   int blocks_needed(int n_tokens) const { return (n_tokens + block_size_ - 1) / block_size_; }
   // Free + evictable blocks.

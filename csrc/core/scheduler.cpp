@@ -53,12 +53,13 @@ bool Scheduler::has_work() const {
 }
 
 bool Scheduler::try_admit(Group& g) {
-  // Chains already promised to admitted groups.
-  int promised = 0;
-  for (int gid : prefilling_) promised += groups_.at(gid).n;
-  for (int gid : running_) promised += groups_.at(gid).n;
-  if (promised + g.n > cfg_.max_batch_seqs) return false;
-  if (budget_used_ + g.budget_blocks > kv_->stats().blocks_total) return false;
+  if (promised_ + g.n > cfg_.max_batch_seqs) return false;
+  if (cfg_.optimistic_admission) {
+    const int need = kv_->blocks_needed(static_cast<int>(g.prompt.size())) + g.n + cfg_.watermark_blocks;
+    if (need > kv_->available_blocks() && promised_ > 0) return false;   // an empty engine always admits
+  } else if (budget_used_ + g.budget_blocks > kv_->stats().blocks_total) {
+    return false;
+  }
   int cached = 0;
   int seq = kv_->create_sequence(g.prompt.data(), static_cast<int>(g.prompt.size()), &cached,
                                  g.kind != RequestKind::Embed);
@@ -69,7 +70,73 @@ bool Scheduler::try_admit(Group& g) {
   g.chains.assign(1, Chain{});
   g.chains[0].seq = seq;
   budget_used_ += g.budget_blocks;
+  promised_ += g.n;
   return true;
+}
+
+void Scheduler::admit_waiting() {
+  if (waiting_.empty() || promised_ >= cfg_.max_batch_seqs) return;
+  int looked = 0;
+  bool passed_head = false;
+  for (auto it = waiting_.begin(); it != waiting_.end() && looked < cfg_.admit_window; ++looked) {
+    const bool is_head = it == waiting_.begin();
+    Group& g = groups_.at(*it);
+    if (try_admit(g)) {
+      prefilling_.push_back(g.id);
+      it = waiting_.erase(it);
+      if (is_head) head_skips_ = 0;
+      else passed_head = true;
+      continue;
+    }
+    if (is_head && head_skips_ >= cfg_.max_head_skips) break;   // the head has waited long enough
+    ++it;
+  }
+  if (passed_head) {
+    ++head_skips_;
+    ++head_skips_total_;
+  }
+}
+
+void Scheduler::preempt(int gid) {
+  Group& g = groups_.at(gid);
+  for (auto& c : g.chains)
+    if (c.seq >= 0) kv_->free_sequence(c.seq);
+  g.chains.clear();
+  g.admitted = g.prefilled = false;
+  g.cached = g.computed = 0;
+  budget_used_ -= g.budget_blocks;
+  promised_ -= g.n;
+  running_.erase(std::remove(running_.begin(), running_.end(), gid), running_.end());
+  prefilling_.erase(std::remove(prefilling_.begin(), prefilling_.end(), gid), prefilling_.end());
+  waiting_.push_front(gid);
+  head_skips_ = 0;
+  ++preemptions_;
+}
+
+void Scheduler::ensure_decode_capacity() {
+  // Oldest groups first; a group that cannot get its blocks takes them from the youngest.
+  for (size_t gi = 0; gi < running_.size(); ++gi) {
+    const int gid = running_[gi];
+    bool restart = true;
+    while (restart) {
+      restart = false;
+      Group& g = groups_.at(gid);
+      for (auto& c : g.chains) {
+        if (c.done || kv_->reserve(c.seq, 1)) continue;
+        // Victims: running groups younger than this one, then half-prefilled prompts, then
+        // (when this is the only group left) nobody: the request alone exceeds the pool.
+        if (running_.size() > gi + 1) {
+          preempt(running_.back());
+        } else if (!prefilling_.empty()) {
+          preempt(prefilling_.back());
+        } else {
+          throw std::runtime_error("Scheduler: KV pool too small for a single running request");
+        }
+        restart = true;
+        break;
+      }
+    }
+  }
 }
 
 namespace {
@@ -89,12 +156,7 @@ void pack_block_tables(StepPlan& plan, const KVManager& kv) {
 
 StepPlan Scheduler::schedule() {
   StepPlan plan;
-  while (!waiting_.empty()) {
-    Group& g = groups_.at(waiting_.front());
-    if (!try_admit(g)) break;
-    prefilling_.push_back(g.id);
-    waiting_.pop_front();
-  }
+  admit_waiting();
   const int bs = kv_->block_size();
 
   if (!prefilling_.empty()) {
@@ -145,7 +207,20 @@ StepPlan Scheduler::schedule() {
       }
       budget -= take;
     }
-    if (cfg_.mix_decode && !plan.seq_ids.empty()) {
+    if (cfg_.mix_decode && !plan.seq_ids.empty() && !running_.empty()) {
+      // Room for the riders' tokens. Only running groups may be preempted here: the prompts
+      // of this step are already laid out in the plan.
+      {
+        std::vector<int> keep_prefilling;
+        keep_prefilling.swap(prefilling_);
+        try {
+          ensure_decode_capacity();
+        } catch (...) {
+          prefilling_.swap(keep_prefilling);
+          throw;
+        }
+        prefilling_.swap(keep_prefilling);
+      }
       const int first = static_cast<int>(plan.seq_ids.size());
       for (int gid : running_) {
         Group& g = groups_.at(gid);
@@ -153,7 +228,7 @@ StepPlan Scheduler::schedule() {
           Chain& c = g.chains[k];
           if (c.done) continue;
           if (!kv_->reserve(c.seq, 1))
-            throw std::runtime_error("Scheduler: KV pool exhausted despite admission budget");
+            throw std::logic_error("Scheduler: block reservation lost between the capacity pass and the plan");
           const int pos = kv_->num_tokens(c.seq);
           const auto& bt = kv_->block_table(c.seq);
           const int row = static_cast<int>(plan.token_ids.size());
@@ -182,6 +257,9 @@ StepPlan Scheduler::schedule() {
   }
 
   if (!running_.empty()) {
+    ensure_decode_capacity();
+  }
+  if (!running_.empty()) {
     plan.kind = StepPlan::Decode;
     for (int gid : running_) {
       Group& g = groups_.at(gid);
@@ -192,7 +270,7 @@ StepPlan Scheduler::schedule() {
         Chain& c = g.chains[k];
         if (c.done) continue;
         if (!kv_->reserve(c.seq, 1))
-          throw std::runtime_error("Scheduler: KV pool exhausted despite admission budget");
+          throw std::logic_error("Scheduler: block reservation lost between the capacity pass and the plan");
         const int pos = kv_->num_tokens(c.seq);
         const auto& bt = kv_->block_table(c.seq);
         plan.seq_ids.push_back(c.seq);
@@ -283,6 +361,7 @@ void Scheduler::maybe_retire(int gid) {
   for (auto& c : g.chains) f.chains.push_back({std::move(c.out), c.cum_logprob, c.reason});
   finished_.push_back(std::move(f));
   budget_used_ -= g.budget_blocks;
+  promised_ -= g.n;
   running_.erase(std::remove(running_.begin(), running_.end(), gid), running_.end());
   prefilling_.erase(std::remove(prefilling_.begin(), prefilling_.end(), gid), prefilling_.end());
   groups_.erase(gid);

@@ -44,6 +44,22 @@ struct SchedulerConfig {
   // for both and a steady flow of requests never alternates between prefill-only and
   // decode-only steps.
   bool mix_decode = false;
+  // Admission walks the waiting queue in arrival order and lets requests that fit pass one
+  // that does not (a long prompt waiting for blocks does not hold up short ones behind it).
+  // `admit_window` bounds how far past the head one schedule() call looks; after the head has
+  // been passed `max_head_skips` times nothing else is admitted until it fits, so it cannot
+  // starve.
+  int admit_window = 64;
+  int max_head_skips = 256;
+  // false: a request is admitted only when the blocks it can need in the worst case (prompt +
+  // every chain's max_new_tokens) are unpromised, so decode never runs out of blocks.
+  // true: a request is admitted when the blocks its PROMPT needs (plus one per chain and
+  // `watermark_blocks`) are available now; when a decode step then finds no block for a chain,
+  // the youngest running request is preempted: its blocks are returned and it goes back to
+  // the head of the waiting queue to be recomputed from its prompt (sampling is keyed by
+  // seed and step index, so it regenerates the same tokens).
+  bool optimistic_admission = false;
+  int watermark_blocks = 0;
 };
 
 enum class FinishReason : uint8_t { Length = 0, Eos = 1, Stop = 2, PrefillOnly = 3, Aborted = 4 };
@@ -134,6 +150,8 @@ class Scheduler {
   bool has_work() const;
   int num_waiting() const { return static_cast<int>(waiting_.size()); }
   int num_running() const;
+  int64_t num_preemptions() const { return preemptions_; }
+  int64_t num_head_skips() const { return head_skips_total_; }
   const SamplingParams& params_of(int request_id) const;
   RequestKind kind_of(int request_id) const;
 
@@ -160,6 +178,11 @@ class Scheduler {
     std::vector<Chain> chains;  // chains[0] owns the prompt sequence until fork
   };
   bool try_admit(Group& g);
+  void admit_waiting();
+  // Makes room for one more token of every live chain of the running groups; preempts from
+  // the youngest running group backwards when the pool is exhausted.
+  void ensure_decode_capacity();
+  void preempt(int gid);
   void finish_chain(Group& g, Chain& c, FinishReason r);
   void maybe_retire(int gid);
   bool is_stop(const Group& g, int32_t tok, FinishReason* why) const;
@@ -173,6 +196,10 @@ class Scheduler {
   std::vector<FinishedRequest> finished_;
   int next_id_ = 0;
   int budget_used_ = 0;
+  int promised_ = 0;            // chains of admitted groups (prefilling_ + running_)
+  int head_skips_ = 0;          // times the current head of waiting_ has been passed
+  int64_t head_skips_total_ = 0;
+  int64_t preemptions_ = 0;
 };
 
 }  // namespace lc

@@ -440,6 +440,11 @@ class Engine:
         for rid in rids:
             self.sched.abort_request(rid)
         self.sched.take_finished()
+        # Prompt blocks enter the prefix cache when their step is scheduled, before the step has
+        # written them; after a failed step such an entry may name KV that was never produced,
+        # and the next prompt with the same prefix would attend over it. Forget them all.
+        self.kvm.take_pending_copies()
+        self.kvm.drop_cache()
         self._reqs.clear()
         self._last_dec = None
         for g in self._graphs.values():
@@ -818,6 +823,8 @@ class Engine:
             "kv.prompt_tokens": k.prompt_tokens, "kv.prefix_hit_tokens": k.prefix_hit_tokens,
             "kv.prefix_hit_rate": k.prefix_hit_tokens / max(1, k.prompt_tokens),
             "kv.cow_copies_total": k.cow_copies, "kv.evictions": k.evictions,
+            "sched.preemptions": self.sched.num_preemptions, "sched.head_skips": self.sched.num_head_skips,
+            "sched.waiting": self.sched.num_waiting, "sched.running": self.sched.num_running,
         })
         return s
 

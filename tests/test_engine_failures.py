@@ -96,3 +96,24 @@ def test_failure_with_several_engines_in_flight_fails_the_batch_not_the_process(
         assert not eng.has_work() and eng.kvm.available_blocks() == eng.kvm.stats().blocks_total
     again = vote.ask_many(["S? A) a B) b C) c D) d"])
     assert again[0].answer in list("ABCD")
+
+
+def test_prompt_reused_after_a_failed_prefill_is_recomputed_not_served_from_unwritten_blocks():
+    """Prompt blocks are registered in the prefix cache when their step is scheduled. If that
+    step dies, the entries must not survive: the same prompt submitted again has to produce
+    what a fresh engine produces."""
+    prompt = "shared persona prefix " * 6 + "and the question"
+    gp = GenParams(temperature=0.0, max_new_tokens=6)
+    fresh, _, _ = _backend()
+    want = fresh.submit_generate(prompt, gp)
+    fresh.run()
+
+    be, eng, model = _backend()
+    _fail_on_call(model, 1)                               # the prefill step itself raises
+    h = be.submit_generate(prompt, gp)
+    be.run()
+    assert h.failed and eng.kvm.stats().blocks_cached == 0
+    again = be.submit_generate(prompt, gp)
+    be.run()
+    assert again.result().cached_tokens == 0
+    assert again.result().token_ids == want.result().token_ids

@@ -188,3 +188,111 @@ def test_prefix_cache_across_requests():
     fin, _ = run_to_completion(sched)
     assert fin[0].cached_tokens == 16
     assert kv.stats().prefix_hit_tokens == 16
+
+
+def test_drop_cache_forgets_entries_and_returns_their_blocks():
+    kv = core.KVManager(16, 4, True)
+    a, _ = kv.create_sequence(toks(9)); kv.commit(a, toks(9))
+    kv.free_sequence(a)
+    assert kv.stats().blocks_cached == 2 and kv.stats().blocks_free == 14
+    kv.drop_cache()
+    assert kv.stats().blocks_cached == 0 and kv.stats().blocks_free == 16
+    b, c = kv.create_sequence(toks(9))
+    assert c == 0                                 # nothing is served from the forgotten entries
+    # entries whose block a live sequence still holds: the sequence keeps the block
+    kv.commit(b, toks(9))
+    kv.drop_cache()
+    assert len(kv.block_table(b)) == 3 and kv.stats().blocks_free == 13
+    kv.free_sequence(b)
+    assert kv.stats().blocks_free == 16
+
+
+def test_freed_cow_destination_cancels_its_copy():
+    kv = core.KVManager(16, 4, False)
+    s, _ = kv.create_sequence(toks(6)); kv.commit(s, toks(6))
+    f = kv.fork(s)
+    assert kv.reserve(f, 1)                       # queues tail copy into a fresh block of f
+    kv.free_sequence(f)                           # ... which is freed before the copy ran
+    assert kv.take_pending_copies() == []
+    kv.free_sequence(s)
+    assert kv.stats().blocks_free == 16
+
+
+def test_admission_skips_ahead_of_a_request_that_does_not_fit_yet():
+    sched, kv = make_sched(blocks=12, bs=4, max_batch=8, max_prefill=64)
+    p = core.SamplingParams(); p.max_new_tokens = 4
+    small = lambda i: sched.add_request(core.RequestKind.Generate, toks(4, 10 * i), 1, p)   # 2 blocks each
+    first = small(0)
+    pbig = core.SamplingParams(); pbig.max_new_tokens = 4
+    big = sched.add_request(core.RequestKind.Generate, toks(40, 500), 1, pbig)             # 11 blocks
+    later = [small(i) for i in range(1, 4)]
+    plan = sched.schedule()
+    # the big request cannot start while `first` holds blocks; the small ones behind it can
+    assert list(plan.request_ids) == [first] + later and sched.num_waiting == 1
+    assert sched.num_head_skips == 1
+    fin, _ = run_to_completion_from(sched, plan)
+    assert {f.request_id for f in fin} == {first, big, *later}
+    assert kv.available_blocks() == 12
+
+
+def test_head_of_queue_is_not_starved_by_skip_ahead():
+    kv = core.KVManager(12, 4, False)
+    cfg = core.SchedulerConfig()
+    cfg.max_batch_seqs, cfg.max_prefill_tokens, cfg.max_head_skips = 8, 64, 2
+    sched = core.Scheduler(kv, cfg)
+    p = core.SamplingParams(); p.max_new_tokens = 4
+    sched.add_request(core.RequestKind.Generate, toks(4), 1, p)
+    big = sched.add_request(core.RequestKind.Generate, toks(40, 500), 1, p)
+    finished_order = []
+    n_small = 1
+    for step in range(400):
+        # a steady stream of small requests that would always fit
+        if step % 2 == 0 and n_small < 40:
+            sched.add_request(core.RequestKind.Generate, toks(4, 1000 + 10 * n_small), 1, p)
+            n_small += 1
+        plan = sched.schedule()
+        if plan.kind == core.StepPlan.Kind.Idle:
+            break
+        finish_step(sched, plan)
+        finished_order += [f.request_id for f in sched.take_finished()]
+    assert big in finished_order
+    assert finished_order.index(big) < len(finished_order) - 10      # well before the stream ran dry
+
+
+def test_optimistic_admission_preempts_and_recomputes_the_youngest():
+    kv = core.KVManager(10, 4, False)
+    cfg = core.SchedulerConfig()
+    cfg.max_batch_seqs, cfg.max_prefill_tokens, cfg.optimistic_admission = 8, 64, True
+    sched = core.Scheduler(kv, cfg)
+    p = core.SamplingParams(); p.max_new_tokens = 12
+    ids = [sched.add_request(core.RequestKind.Generate, toks(6, 7 * i), 1, p) for i in range(4)]
+    # worst case 4 x 5 = 20 blocks > 10: conservative admission would hold two back
+    plan = sched.schedule()
+    assert len(plan.seq_ids) == 4
+    fin, steps = run_to_completion_from(sched, plan)
+    assert sched.num_preemptions >= 1
+    assert sorted(f.request_id for f in fin) == ids
+    for f in fin:                                  # a recomputed request regenerates the same tokens
+        t = f.chains[0].tokens
+        assert len(t) == 12 and all((t[i + 1] - t[i]) % 50 == 1 for i in range(11))
+    assert kv.available_blocks() == 10
+
+
+def finish_step(sched, plan, vocab=50):
+    if plan.kind == core.StepPlan.Kind.Prefill:
+        slots = sched.prefill_sample_layout(plan)
+        first = [(int(plan.token_ids[plan.last_rows[s.last_row_index]]) + 1 + s.chain) % vocab for s in slots]
+        rf = plan.rider_first
+        if rf >= 0:
+            first += [int(t + 1) % vocab for t in plan.token_ids[plan.cu_q[rf:-1]]]
+        sched.complete_prefill(plan, np.array(first, dtype=np.int32), np.zeros(len(first), dtype=np.float32))
+    else:
+        nxt = (plan.token_ids + 1) % vocab
+        sched.complete_decode(plan, nxt.astype(np.int32), np.zeros(len(nxt), dtype=np.float32))
+
+
+def run_to_completion_from(sched, plan):
+    finish_step(sched, plan)
+    fin = sched.take_finished()
+    more, steps = run_to_completion(sched)
+    return fin + more, steps
