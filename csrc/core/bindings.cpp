@@ -159,12 +159,16 @@ PYBIND11_MODULE(_core, m) {
       py::arg("weights") = py::none());
   m.def(
       "majority_vote_batch",
-      [](i32arr votes, int num_classes, TieBreak tie) {
+      [](i32arr votes, int num_classes, TieBreak tie, py::object weights) {
         if (votes.ndim() != 2) throw std::invalid_argument("majority_vote_batch: votes must be [R, N]");
-        return majority_vote_batch(votes.data(), static_cast<int>(votes.shape(0)),
-                                   static_cast<int>(votes.shape(1)), num_classes, tie);
+        const int R = static_cast<int>(votes.shape(0)), N = static_cast<int>(votes.shape(1));
+        if (weights.is_none()) return majority_vote_batch(votes.data(), R, N, num_classes, tie);
+        f32arr w = weights.cast<f32arr>();
+        if (w.size() != N) throw std::invalid_argument("majority_vote_batch: need one weight per voter");
+        return majority_vote_batch(votes.data(), R, N, num_classes, tie, w.data());
       },
-      py::arg("votes"), py::arg("num_classes"), py::arg("tie") = TieBreak::LowestClass);
+      py::arg("votes"), py::arg("num_classes"), py::arg("tie") = TieBreak::LowestClass,
+      py::arg("weights") = py::none());
   py::class_<MedoidResult>(m, "MedoidResult")
       .def_readonly("index", &MedoidResult::index)
       .def_readonly("score", &MedoidResult::score)

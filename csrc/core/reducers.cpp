@@ -9,17 +9,22 @@ VoteResult majority_vote(const int32_t* votes, int n, int num_classes, TieBreak 
   VoteResult r;
   if (n <= 0 || num_classes <= 0) return r;
   std::vector<int> cnt(num_classes, 0);
-  std::vector<double> wsum(num_classes, 0.0);
+  std::vector<float> wsum(num_classes, 0.f);   // float, voter order: the device kernel sums the same way
   std::vector<int> first(num_classes, n);
   for (int i = 0; i < n; ++i) {
     int c = votes[i];
     if (c < 0 || c >= num_classes) continue;
     ++cnt[c];
-    wsum[c] += weights ? weights[i] : 1.0;
+    wsum[c] += weights ? weights[i] : 1.f;
     if (first[c] == n) first[c] = i;
     ++r.valid;
   }
   if (r.valid == 0) return r;
+  // Ranking keys. Weights with LowestClass / FirstVoter: a weighted plurality (weight sum, then
+  // count, then the tie rule). HighestWeight: plurality by count, ties go to the larger weight
+  // sum, then the lower class. No weights: count, then the tie rule.
+  const bool weighted_primary = weights && tie != TieBreak::HighestWeight;
+  const bool weight_secondary = tie == TieBreak::HighestWeight;
   int best = -1;
   for (int c = 0; c < num_classes; ++c) {
     if (cnt[c] == 0) continue;
@@ -27,20 +32,14 @@ VoteResult majority_vote(const int32_t* votes, int n, int num_classes, TieBreak 
       best = c;
       continue;
     }
+    const float k1c = weighted_primary ? wsum[c] : static_cast<float>(cnt[c]);
+    const float k1b = weighted_primary ? wsum[best] : static_cast<float>(cnt[best]);
+    const float k2c = weighted_primary ? static_cast<float>(cnt[c]) : (weight_secondary ? wsum[c] : 0.f);
+    const float k2b = weighted_primary ? static_cast<float>(cnt[best]) : (weight_secondary ? wsum[best] : 0.f);
     bool better;
-    if (weights) {
-      // weighted vote: compare weight sums first, then counts
-      if (wsum[c] != wsum[best]) better = wsum[c] > wsum[best];
-      else if (cnt[c] != cnt[best]) better = cnt[c] > cnt[best];
-      else better = (tie == TieBreak::FirstVoter) ? first[c] < first[best] : false;
-    } else if (cnt[c] != cnt[best]) {
-      better = cnt[c] > cnt[best];
-    } else {
-      switch (tie) {
-        case TieBreak::FirstVoter: better = first[c] < first[best]; break;
-        default: better = false;  // LowestClass / HighestWeight(unweighted): keep the lower id
-      }
-    }
+    if (k1c != k1b) better = k1c > k1b;
+    else if (k2c != k2b) better = k2c > k2b;
+    else better = (tie == TieBreak::FirstVoter) ? first[c] < first[best] : false;   // else keep the lower id
     if (better) best = c;
   }
   r.winner = best;
@@ -51,10 +50,10 @@ VoteResult majority_vote(const int32_t* votes, int n, int num_classes, TieBreak 
 }
 
 std::vector<VoteResult> majority_vote_batch(const int32_t* votes, int R, int N, int num_classes,
-                                            TieBreak tie) {
+                                            TieBreak tie, const float* weights) {
   std::vector<VoteResult> out(R);
   for (int r = 0; r < R; ++r)
-    out[r] = majority_vote(votes + static_cast<size_t>(r) * N, N, num_classes, tie);
+    out[r] = majority_vote(votes + static_cast<size_t>(r) * N, N, num_classes, tie, weights);
   return out;
 }
 

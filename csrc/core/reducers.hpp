@@ -14,7 +14,7 @@ namespace lc {
 enum class TieBreak : uint8_t {
   LowestClass = 0,   // smallest class id among the tied
   FirstVoter = 1,    // class of the earliest voter (member order) among the tied
-  HighestWeight = 2, // largest summed weight (falls back to LowestClass when unweighted)
+  HighestWeight = 2, // plurality by count; ties go to the larger summed weight, then the lower class
 };
 
 struct VoteResult {
@@ -25,13 +25,16 @@ struct VoteResult {
   bool unanimous = false;
 };
 
-// votes[i] in [0, num_classes) or -1 (unparsed / abstain). weights may be null.
+// votes[i] in [0, num_classes) or -1 (unparsed / abstain). weights (one per voter) may be
+// null. With weights and LowestClass / FirstVoter the vote is a weighted plurality (largest
+// weight sum wins, then the larger count, then the tie rule); with HighestWeight the weights
+// only break ties in count. count / agreement / unanimous always count voters.
 VoteResult majority_vote(const int32_t* votes, int n, int num_classes, TieBreak tie,
                          const float* weights = nullptr);
 
-// Batched: votes is [R, N] row-major.
+// Batched: votes is [R, N] row-major; weights [N] (the voters are the same in every row) or null.
 std::vector<VoteResult> majority_vote_batch(const int32_t* votes, int R, int N, int num_classes,
-                                            TieBreak tie);
+                                            TieBreak tie, const float* weights = nullptr);
 
 struct MedoidResult {
   int index = -1;          // row with the largest summed cosine similarity to the others

@@ -699,12 +699,11 @@ LC_EXPORT int lc_attn_prefix(const void* Q, int q_stride, const void* Kc, const 
       static_cast<float*>(part_o), static_cast<float*>(part_lse), np_total, slot0, Hq, Hkv, lbs, scale2
   if (waves == 4) {
     const size_t lds = sizeof(float) * 4 * 32 * (Dh + 2);
-    static bool attr_set = false;
-    if (!attr_set) {
-      hipFuncSetAttribute(reinterpret_cast<const void*>(attn_prefix_mw_kernel<128, 4>),
+    static LcDeviceOnce attr_once;
+    attr_once.run([&] {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_prefix_mw_kernel<128, 4>),
                           hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(sizeof(float) * 4 * 32 * 130));
-      attr_set = true;
-    }
+    });
     if (Dh == 128) attn_prefix_mw_kernel<128, 4><<<grid, dim3(256), lds, stream>>>(LC_ARGS);
     else attn_prefix_mw_kernel<64, 4><<<grid, dim3(256), lds, stream>>>(LC_ARGS);
   } else if (Dh == 128) {

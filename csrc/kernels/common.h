@@ -9,6 +9,7 @@
 #include <stdint.h>
 
 #include <algorithm>
+#include <atomic>
 
 typedef uint16_t bf16_t;  // raw bfloat16 bits
 typedef __attribute__((ext_vector_type(8))) short bf16x8;   // one MFMA A/B fragment (4 VGPRs)
@@ -96,6 +97,23 @@ LC_DEVICE float rng_uniform(uint64_t seed, uint32_t step, uint32_t counter) {
   z = mix64(z ^ ((static_cast<uint64_t>(step) << 32) | counter));
   return (static_cast<float>(z >> 40) + 0.5f) * (1.0f / 16777216.0f);  // (0,1)
 }
+
+// Per-device, thread-safe "do this once" for launch attributes (the dynamic-LDS limit of a
+// kernel is a per-device property, and launchers are called from several host threads: one
+// per engine stream, one per loopback rank). The guarded call must be idempotent: two threads
+// that race on a device's first launch may both run it.
+struct LcDeviceOnce {
+  std::atomic<uint8_t> done[64];
+  template <class F>
+  void run(F&& f) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    dev &= 63;
+    if (done[dev].load(std::memory_order_acquire)) return;
+    f();
+    done[dev].store(1, std::memory_order_release);
+  }
+};
 
 #define LC_EXPORT extern "C" __attribute__((visibility("default")))
 

@@ -13,8 +13,12 @@
 
 namespace {
 
-// tie: 0 = lowest class id, 1 = class of the earliest voter
-__global__ void majority_vote_kernel(const int32_t* __restrict__ votes, int R, int N, int num_classes,
+// tie: 0 = lowest class id, 1 = class of the earliest voter, 2 = larger weight sum (then lower id).
+// weights [N] or null: with tie 0 / 1 the ranking is by weight sum, then count, then the tie
+// rule (weighted plurality); with tie 2 by count, then weight sum. Same keys, same float
+// summation order (voter order) as lc::majority_vote on the host.
+__global__ void majority_vote_kernel(const int32_t* __restrict__ votes, const float* __restrict__ weights,
+                                     int R, int N, int num_classes,
                                      int tie, int32_t* __restrict__ winner, int32_t* __restrict__ count,
                                      int32_t* __restrict__ valid, float* __restrict__ agreement,
                                      int32_t* __restrict__ unanimous) {
@@ -36,23 +40,38 @@ __global__ void majority_vote_kernel(const int32_t* __restrict__ votes, int R, i
       }
     }
   }
-  // arg-max over lanes (classes): larger count wins; ties by lower class or earlier voter
+  float my_w = static_cast<float>(my_count);
+  if (weights != nullptr) {
+    my_w = 0.f;
+    if (lane < num_classes && my_count > 0)
+      for (int i = 0; i < N; ++i)
+        if (row[i] == lane) my_w += weights[i];
+  }
+  const bool weighted_primary = weights != nullptr && tie != 2;
+  // arg-max over lanes (classes) on (key1, key2), then lower class or earlier voter
   int best_c = lane < num_classes && my_count > 0 ? lane : -1;
   int best_n = lane < num_classes ? my_count : 0;
   int best_f = my_first;
+  float best_k1 = weighted_primary ? my_w : static_cast<float>(my_count);
+  float best_k2 = weighted_primary ? static_cast<float>(my_count) : (tie == 2 ? my_w : 0.f);
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) {
     const int oc = __shfl_xor(best_c, off, 64), on = __shfl_xor(best_n, off, 64),
               of = __shfl_xor(best_f, off, 64);
+    const float ok1 = __shfl_xor(best_k1, off, 64), ok2 = __shfl_xor(best_k2, off, 64);
     bool take = false;
     if (oc >= 0) {
-      if (best_c < 0 || on > best_n) take = true;
-      else if (on == best_n) take = tie == 1 ? (of < best_f) : (oc < best_c);
+      if (best_c < 0) take = true;
+      else if (ok1 != best_k1) take = ok1 > best_k1;
+      else if (ok2 != best_k2) take = ok2 > best_k2;
+      else take = tie == 1 ? (of < best_f) : (oc < best_c);
     }
     if (take) {
       best_c = oc;
       best_n = on;
       best_f = of;
+      best_k1 = ok1;
+      best_k2 = ok2;
     }
   }
   if (lane == 0) {
@@ -238,11 +257,12 @@ LC_EXPORT int lc_answer_extract(const void* ids, const void* lens, int R, int ld
 
 LC_EXPORT int lc_majority_vote(const void* votes, int R, int N, int num_classes, int tie, void* winner,
                                void* count, void* valid, void* agreement, void* unanimous,
-                               hipStream_t stream) {
+                               const void* weights, hipStream_t stream) {
   if (R <= 0) return 0;
-  if (num_classes < 1 || num_classes > 64) return -1;
+  if (num_classes < 1 || num_classes > 64 || tie < 0 || tie > 2) return -1;
   majority_vote_kernel<<<dim3((R + 3) / 4), dim3(256), 0, stream>>>(
-      static_cast<const int32_t*>(votes), R, N, num_classes, tie, static_cast<int32_t*>(winner),
+      static_cast<const int32_t*>(votes), static_cast<const float*>(weights), R, N, num_classes, tie,
+      static_cast<int32_t*>(winner),
       static_cast<int32_t*>(count), static_cast<int32_t*>(valid), static_cast<float*>(agreement),
       static_cast<int32_t*>(unanimous));
   LC_RETURN_LAST_ERROR();

@@ -164,31 +164,55 @@ __global__ void copy_blocks_kernel(char* __restrict__ base, const int32_t* __res
   for (size_t i = threadIdx.x; i < block_bytes / 16; i += blockDim.x) d[i] = s[i];
 }
 
-// Pooled, L2-normalised sentence embedding. One block per sequence.
-// mode 0: mean over the sequence's rows [cu[s], cu[s+1]); mode 1: last row only.
-__global__ void embed_pool_kernel(const bf16_t* __restrict__ hidden, const int32_t* __restrict__ cu,
-                                  float* __restrict__ out, int d, int mode) {
+// Pooled sentence embedding, one block per sequence, 8 columns (16 B) per lane and load.
+// Rows [begin[s], end[s]) of `hidden` belong to sequence s.
+// mode 0: mean over the rows, L2-normalised; mode 1: last row, L2-normalised; mode 2: plain
+// fp32 sum of the rows (a prompt prefilled in several chunks adds its chunk sums and
+// normalises once at the end: l2_normalize_kernel).
+__global__ __launch_bounds__(256) void embed_pool_kernel(const bf16_t* __restrict__ hidden,
+                                                         const int32_t* __restrict__ begin,
+                                                         const int32_t* __restrict__ end,
+                                                         float* __restrict__ out, int d, int mode) {
   __shared__ float red[16];
   const int s = blockIdx.x;
-  const int r0 = cu[s], r1 = cu[s + 1];
+  const int r0 = begin[s], r1 = end[s];
   const int n = r1 - r0;
   float ss = 0.f;
-  for (int c = threadIdx.x; c < d; c += blockDim.x) {
-    float acc = 0.f;
+  for (int c = threadIdx.x * 8; c < d; c += blockDim.x * 8) {
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     if (n > 0) {
-      if (mode == 1) {
-        acc = bf16_to_f32(hidden[static_cast<size_t>(r1 - 1) * d + c]);
-      } else {
-        for (int r = r0; r < r1; ++r) acc += bf16_to_f32(hidden[static_cast<size_t>(r) * d + c]);
-        acc /= static_cast<float>(n);
+      for (int r = (mode == 1 ? r1 - 1 : r0); r < r1; ++r) {
+        const bf16x8 v = *reinterpret_cast<const bf16x8*>(hidden + static_cast<size_t>(r) * d + c);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] += bf16_to_f32(static_cast<bf16_t>(v[j]));
+      }
+      if (mode == 0) {
+        const float inv_n = 1.f / static_cast<float>(n);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] *= inv_n;
       }
     }
-    out[static_cast<size_t>(s) * d + c] = acc;
-    ss += acc * acc;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      out[static_cast<size_t>(s) * d + c + j] = acc[j];
+      ss += acc[j] * acc[j];
+    }
   }
+  if (mode == 2) return;
   ss = block_sum(ss, red);
   const float inv = ss > 0.f ? rsqrtf(ss) : 0.f;
   for (int c = threadIdx.x; c < d; c += blockDim.x) out[static_cast<size_t>(s) * d + c] *= inv;
+}
+
+// y[r, :] = x[r, :] / |x[r, :]| (fp32 rows; zero rows stay zero). One block per row.
+__global__ __launch_bounds__(256) void l2_normalize_kernel(const float* __restrict__ x, float* __restrict__ y, int d) {
+  __shared__ float red[16];
+  const float* xr = x + static_cast<size_t>(blockIdx.x) * d;
+  float ss = 0.f;
+  for (int c = threadIdx.x; c < d; c += blockDim.x) ss += xr[c] * xr[c];
+  ss = block_sum(ss, red);
+  const float inv = ss > 0.f ? rsqrtf(ss) : 0.f;
+  for (int c = threadIdx.x; c < d; c += blockDim.x) y[static_cast<size_t>(blockIdx.x) * d + c] = xr[c] * inv;
 }
 
 }  // namespace
@@ -257,10 +281,18 @@ LC_EXPORT int lc_copy_blocks(void* base, const void* src, const void* dst, int n
   LC_RETURN_LAST_ERROR();
 }
 
-LC_EXPORT int lc_embed_pool(const void* hidden, const void* cu, void* out, int n_seqs, int d, int mode,
-                            hipStream_t stream) {
+LC_EXPORT int lc_embed_pool(const void* hidden, const void* begin, const void* end, void* out, int n_seqs, int d,
+                            int mode, hipStream_t stream) {
   if (n_seqs <= 0) return 0;
+  if (d % 8 || mode < 0 || mode > 2) return -1;
   embed_pool_kernel<<<dim3(n_seqs), dim3(256), 0, stream>>>(
-      static_cast<const bf16_t*>(hidden), static_cast<const int32_t*>(cu), static_cast<float*>(out), d, mode);
+      static_cast<const bf16_t*>(hidden), static_cast<const int32_t*>(begin), static_cast<const int32_t*>(end),
+      static_cast<float*>(out), d, mode);
+  LC_RETURN_LAST_ERROR();
+}
+
+LC_EXPORT int lc_l2_normalize(const void* x, void* y, int rows, int d, hipStream_t stream) {
+  if (rows <= 0) return 0;
+  l2_normalize_kernel<<<dim3(rows), dim3(256), 0, stream>>>(static_cast<const float*>(x), static_cast<float*>(y), d);
   LC_RETURN_LAST_ERROR();
 }

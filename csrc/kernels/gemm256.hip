@@ -311,16 +311,15 @@ LC_EXPORT int lc_gemm256(const void* Wp, const void* X, void* Y, const void* bia
   auto w = static_cast<const bf16_t*>(Wp);
   auto x = static_cast<const bf16_t*>(X);
   auto b = static_cast<const bf16_t*>(bias);
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256_kernel<EPI_BF16>),
+  static LcDeviceOnce attr_once;
+  attr_once.run([&] {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256_kernel<EPI_BF16>),
                         hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
-    hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256_kernel<EPI_F32>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256_kernel<EPI_F32>),
                         hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
-    hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256_kernel<EPI_SWIGLU>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256_kernel<EPI_SWIGLU>),
                         hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
-    attr_set = true;
-  }
+  });
   if (epi == EPI_BF16)
     gemm256_kernel<EPI_BF16><<<grid, block, lds, stream>>>(w, x, Y, b, M, N, K, ldy, tiles_m, tiles_n);
   else if (epi == EPI_F32)
@@ -345,14 +344,13 @@ LC_EXPORT int lc_gemm256_grouped(const void* Wp_all, long long expert_stride, co
   auto w = static_cast<const bf16_t*>(Wp_all);
   auto x = static_cast<const bf16_t*>(X);
   auto off = static_cast<const int32_t*>(offsets);
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256_kernel<EPI_BF16, true>),
+  static LcDeviceOnce attr_once;
+  attr_once.run([&] {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256_kernel<EPI_BF16, true>),
                         hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
-    hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256_kernel<EPI_SWIGLU, true>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256_kernel<EPI_SWIGLU, true>),
                         hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
-    attr_set = true;
-  }
+  });
   if (epi == EPI_BF16)
     gemm256_kernel<EPI_BF16, true><<<grid, block, lds, stream>>>(w, x, Y, nullptr, total_rows, N, K, ldy, tiles_m,
                                                                  tiles_n, expert_stride, off, E);
@@ -373,12 +371,11 @@ LC_EXPORT int lc_gemm256_splitk(const void* Wp, const void* X, void* Y, int M, i
   const int tiles_m = (M + G2_BM - 1) / G2_BM, tiles_n = n_pad / G2_BN;
   const dim3 grid(tiles_m * tiles_n, splits), block(512);
   const size_t lds = 2 * G2_STAGE;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256_kernel<EPI_F32>),
+  static LcDeviceOnce attr_once;
+  attr_once.run([&] {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256_kernel<EPI_F32>),
                         hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
-    attr_set = true;
-  }
+  });
   gemm256_kernel<EPI_F32><<<grid, block, lds, stream>>>(static_cast<const bf16_t*>(Wp), static_cast<const bf16_t*>(X), Y,
                                                         nullptr, M, N, K, ldy, tiles_m, tiles_n, 0, nullptr, 0,
                                                         (K / G2_BK) / splits);

@@ -278,16 +278,15 @@ int launch_panel(int epi, const bf16_t* w, const bf16_t* x, void* Y, const bf16_
   const dim3 grid(n_pad / GP_BN, splits), block(512);
   const int lds = S::NSTAGE * S::STAGE;
   const int nk = (K / GP_BK) / splits;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_panel_kernel<BM, DEEP, EPI_BF16>),
+  static LcDeviceOnce attr_once;
+  attr_once.run([&] {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_panel_kernel<BM, DEEP, EPI_BF16>),
                         hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_panel_kernel<BM, DEEP, EPI_F32>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_panel_kernel<BM, DEEP, EPI_F32>),
                         hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_panel_kernel<BM, DEEP, EPI_SWIGLU>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_panel_kernel<BM, DEEP, EPI_SWIGLU>),
                         hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    attr_set = true;
-  }
+  });
   if (epi == EPI_BF16)
     gemm_panel_kernel<BM, DEEP, EPI_BF16><<<grid, block, lds, stream>>>(w, x, Y, b, M, N, K, ldy, nk);
   else if (epi == EPI_F32)
@@ -418,14 +417,13 @@ int launch_panel_grouped(int epi, const bf16_t* w, long long stride, const bf16_
   using S = PanelShape<BM, true>;
   const dim3 grid(n_pad / GP_BN, (total_rows + BM - 1) / BM, E), block(512);
   const int lds = S::NSTAGE * S::STAGE;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_panel_grouped_kernel<BM, EPI_BF16>),
+  static LcDeviceOnce attr_once;
+  attr_once.run([&] {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_panel_grouped_kernel<BM, EPI_BF16>),
                         hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_panel_grouped_kernel<BM, EPI_SWIGLU>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_panel_grouped_kernel<BM, EPI_SWIGLU>),
                         hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    attr_set = true;
-  }
+  });
   if (epi == EPI_BF16)
     gemm_panel_grouped_kernel<BM, EPI_BF16><<<grid, block, lds, stream>>>(w, stride, x, ri, off, Y, N, K, ldy);
   else if (epi == EPI_SWIGLU)

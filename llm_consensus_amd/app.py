@@ -108,11 +108,12 @@ def build_backend(spec: ModelSpec, device: torch.device, comm=None, tp_rank: int
     grouped = comm is not None and comm.world > 1
     model = build_model(spec, device, tp_rank=tp_rank, tp_size=spec.tp if grouped else 1, comm=comm,
                         ep_size=spec.ep if grouped else 1, ep_mode=spec.ep_mode)
-    max_len = min(model.cfg.max_position, 4096)
+    max_len = min(model.cfg.max_position, spec.max_model_len) if spec.max_model_len > 0 else model.cfg.max_position
     eng = Engine(model, block_size=spec.kv_block_size if device.type == "cuda" else 16,
                  max_batch_seqs=spec.max_batch_seqs, max_prefill_tokens=spec.max_prefill_tokens,
                  max_model_len=max_len, kv_fraction=spec.kv_fraction,
                  graph_buckets=spec.graph_batch_buckets, name=spec.name, mix_decode=spec.mix_decode,
+                 optimistic_admission=spec.admission == "optimistic",
                  num_kv_blocks=None if device.type == "cuda" else 512)
     tok = make_tokenizer(spec.tokenizer, model.cfg.vocab_size)
     return EngineBackend(eng, tok, name=spec.name, stop_at_eos=spec.tokenizer is not None,

@@ -99,6 +99,14 @@ def main(argv: Optional[list] = None) -> int:
     args = ap.parse_args(argv)
 
     cfg: ConsensusConfig = load_config(args.config)
+    random_init = sorted({m.model for m in cfg.members if not cfg.models[m.model].path})
+    if random_init:
+        # The reference refuses to start without a usable backend (main.rs:354-357). Random
+        # weights are a usable engine but not a usable oracle: say so before the first answer.
+        msg = (f"warning: model(s) {', '.join(random_init)} have no checkpoint path: running RANDOM-INIT weights, "
+               "answers are noise (set models.<name>.path in --config / $CONSENSUS_CONFIG)")
+        log.warning(msg)
+        print(msg, file=sys.stderr, flush=True)
     if args.strategy:
         cfg.strategy = args.strategy
         cfg.validate()

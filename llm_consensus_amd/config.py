@@ -46,16 +46,16 @@ class ModelSpec:
     name: str = "default"
     path: Optional[str] = None
     preset: Optional[str] = "tiny-llama"
-    dtype: str = "bf16"
     tp: int = 1
     ep: int = 1
     ep_mode: str = "allreduce"        # allreduce | a2a (see parallel/ep.py)
-    devices: Optional[List[int]] = None
     kv_block_size: int = 64
     kv_fraction: float = 0.6          # share of free HBM given to the KV pool
     max_batch_seqs: int = 256
     max_prefill_tokens: int = 8192
-    mix_decode: bool = False          # decoding chains ride along in the steps that prefill new prompts
+    mix_decode: bool = True           # decoding chains ride along in the steps that prefill new prompts
+    admission: str = "reserve"        # reserve (worst-case blocks promised up front) | optimistic (preempt + recompute)
+    max_model_len: int = 0            # longest prompt + answer served; 0 = the model's max_position
     graph_batch_buckets: List[int] = field(default_factory=lambda: [1, 2, 4, 8, 16, 32, 64, 128, 256])
     tokenizer: Optional[str] = None   # HF tokenizer dir; None => byte-level fallback
     chat_format: str = "none"         # none | llama3 | chatml | mistral: turn markers around each prompt
@@ -76,7 +76,7 @@ class MemberConfig:
 class ConsensusConfig:
     strategy: str = "reference_protocol"
     max_rounds: int = 5
-    proposer_policy: str = "random"   # random | round_robin | fixed | all
+    proposer_policy: str = "random"   # random | round_robin | fixed
     fixed_proposer: int = 0
     failure_policy: str = "abstain"   # abstain | needs_refinement
     parse_mode: str = "strict"        # strict | tolerant
@@ -110,8 +110,12 @@ class ConsensusConfig:
             raise ValueError(f"unknown strategy {self.strategy!r}; expected one of {STRATEGIES}")
         if self.max_rounds < 1:
             raise ValueError("max_rounds must be >= 1")
-        if self.proposer_policy not in ("random", "round_robin", "fixed", "all"):
-            raise ValueError(f"unknown proposer_policy {self.proposer_policy!r}")
+        if self.proposer_policy not in ("random", "round_robin", "fixed"):
+            raise ValueError(f"unknown proposer_policy {self.proposer_policy!r} (random | round_robin | fixed; "
+                             "the vote strategies already ask every member)")
+        for spec in self.models.values():
+            if spec.admission not in ("reserve", "optimistic"):
+                raise ValueError(f"model {spec.name!r}: unknown admission {spec.admission!r}")
         if self.failure_policy not in ("abstain", "needs_refinement"):
             raise ValueError(f"unknown failure_policy {self.failure_policy!r}")
         if self.parse_mode not in ("strict", "tolerant"):
@@ -134,7 +138,6 @@ class ConsensusConfig:
             "random": core.ProposerPolicy.Random,
             "round_robin": core.ProposerPolicy.RoundRobin,
             "fixed": core.ProposerPolicy.Fixed,
-            "all": core.ProposerPolicy.RoundRobin,
         }[self.proposer_policy]
         sc.fixed_proposer = self.fixed_proposer
         sc.failure_policy = (

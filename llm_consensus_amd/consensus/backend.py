@@ -56,8 +56,10 @@ class Handle:
         self.finished_at: Optional[float] = None
         self.tag = tag
 
-    def set_result(self, value: Any) -> None:
-        self._value, self._done, self.finished_at = value, True, time.perf_counter()
+    def set_result(self, value: Any, at: Optional[float] = None) -> None:
+        """``at``: when the result became available (perf_counter), if the backend knows better
+        than "now" (an engine finishes requests long before a batch driver collects them)."""
+        self._value, self._done, self.finished_at = value, True, (at if at is not None else time.perf_counter())
 
     def set_error(self, err: BaseException) -> None:
         self._error, self._done, self.finished_at = err, True, time.perf_counter()

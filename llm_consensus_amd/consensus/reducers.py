@@ -38,15 +38,22 @@ def _is_gpu(device) -> bool:
 
 
 def majority_vote_batch(votes: np.ndarray, num_classes: int,
-                        tie: "core.TieBreak" = core.TieBreak.LowestClass, device=None) -> VoteBatch:
+                        tie: "core.TieBreak" = core.TieBreak.LowestClass, device=None,
+                        weights: Optional[np.ndarray] = None) -> VoteBatch:
+    """``weights`` [N]: one per voter (member weights). With them the vote is a weighted
+    plurality, or (``tie`` = HighestWeight) a plurality whose ties go to the heavier side."""
     votes = np.ascontiguousarray(votes, dtype=np.int32)
     if votes.ndim != 2:
         raise ValueError("votes must be [R, N]")
+    if weights is not None:
+        weights = np.ascontiguousarray(weights, dtype=np.float32)
+        if weights.shape != (votes.shape[1],):
+            raise ValueError("weights must hold one value per voter")
     if _is_gpu(device):
         from ..ops import consensus_ops
 
-        return consensus_ops.majority_vote_device(votes, num_classes, tie, device)
-    res = core.majority_vote_batch(votes, num_classes, tie)
+        return consensus_ops.majority_vote_device(votes, num_classes, tie, device, weights)
+    res = core.majority_vote_batch(votes, num_classes, tie, weights)
     return VoteBatch(
         winner=np.array([r.winner for r in res], dtype=np.int32),
         count=np.array([r.count for r in res], dtype=np.int32),

@@ -90,8 +90,12 @@ class MajorityVote:
                 texts[r][i] = res.texts[0]
                 dec = res.decision_logprobs[0] if res.decision_logprobs else None
                 votes[r, i] = _classify(res.texts[0], dec, self.choices)
+        # Member weights (MemberConfig.weight): all equal => a plain plurality.
+        w = np.array([float(getattr(m, "weight", 1.0)) for m in self.members], dtype=np.float32)
+        weights = w if (w != w[0]).any() else None
         with span("reduce", "strategy"):
-            red = reducers.majority_vote_batch(votes, len(self.choices), self.tie_break, device=self.device)
+            red = reducers.majority_vote_batch(votes, len(self.choices), self.tie_break, device=self.device,
+                                               weights=weights)
         dt = time.perf_counter() - t0
         out = []
         for r, q in enumerate(questions):

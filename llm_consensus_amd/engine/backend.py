@@ -137,11 +137,11 @@ class EngineBackend(Backend):
                     texts.append(self.tok.decode(toks))
                 h.set_result(GenResult(texts=texts, token_ids=out.token_ids, cum_logprobs=out.cum_logprobs,
                                        decision_logprobs=out.decision_logprobs, prompt_tokens=out.prompt_len,
-                                       cached_tokens=out.cached_tokens))
+                                       cached_tokens=out.cached_tokens), at=out.finished_at)
             elif kind == "score":
-                h.set_result(out.scores)
+                h.set_result(out.scores, at=out.finished_at)
             else:
-                h.set_result(out.embedding)
+                h.set_result(out.embedding, at=out.finished_at)
 
     def engines(self) -> list:
         return [self.engine] if self._pending else []

@@ -84,9 +84,9 @@ class _KeepAlive(torch.utils._python_dispatch.TorchDispatchMode):
 class _DecodeGraph:
     """Static buffers + captured graph of one decode step for a batch bucket."""
 
-    def __init__(self, eng: "Engine", bucket: int, with_prefix: bool) -> None:
+    def __init__(self, eng: "Engine", bucket: int, with_prefix: bool, ctx_class: int) -> None:
         dev = eng.device
-        self.bucket, self.with_prefix = bucket, with_prefix
+        self.bucket, self.with_prefix, self.ctx_class = bucket, with_prefix, ctx_class
         self.gmax = max(1, bucket // 2)
         B, MB, C, G = bucket, eng.max_blocks_cap, eng.max_decision, self.gmax
         # All per-step inputs live in ONE int32 arena: a pinned host mirror is filled with
@@ -119,11 +119,11 @@ class _DecodeGraph:
             off += n
         self.h["slot_mapping"][:] = -1
         self.h["top_p"][:] = 1.0
-        self.nsplit = ops.choose_kv_splits(bucket, eng.model.hkv, eng.nominal_ctx)
+        self.nsplit = ops.choose_kv_splits(bucket, eng.model.hkv, ctx_class)
         # The shared-prefix pass scans each group's prompt once per kv head; a block that walks
         # the whole prompt alone is a chain of dependent loads, so the prompt is cut into ~128-key
         # pieces. Blocks of the (statically sized) group slots that are empty at run time exit at once.
-        self.prefix_splits = max(1, min(8, eng.nominal_ctx // 128))
+        self.prefix_splits = max(1, min(8, ctx_class // 128))
         self.graph: Optional[torch.cuda.CUDAGraph] = None
         self.pieces: Optional[List[tuple]] = None
         self.lists = False
@@ -345,7 +345,8 @@ class Engine:
                  max_batch_seqs: int = 256, max_prefill_tokens: int = 8192, max_model_len: int = 4096,
                  kv_fraction: float = 0.6, enable_prefix_cache: bool = True, use_graphs: Optional[bool] = None,
                  graph_buckets: Sequence[int] = (1, 2, 4, 8, 16, 32, 64, 128, 256), max_decision: int = 8,
-                 max_group_rows: int = 16, name: str = "engine", mix_decode: bool = False) -> None:
+                 max_group_rows: int = 16, name: str = "engine", mix_decode: bool = True,
+                 optimistic_admission: bool = False) -> None:
         self.model, self.device, self.name = model, model.device, name
         cfg = model.cfg
         self.block_size = block_size
@@ -362,13 +363,18 @@ class Engine:
         sc = core.SchedulerConfig()
         sc.max_batch_seqs, sc.max_prefill_tokens = max_batch_seqs, max_prefill_tokens
         # Mixed steps: chains that are already decoding ride along in the steps that prefill newly
-        # arrived prompts (one pass over the weights serves both). Meant for a steady flow of
-        # requests; a single batch that arrives together gains nothing from it.
+        # arrived prompts (one pass over the weights serves both), so a steady flow of arrivals
+        # never starves the chains that are already generating.
         sc.mix_decode = mix_decode
+        sc.optimistic_admission = optimistic_admission
         self.sched = core.Scheduler(self.kvm, sc)
         self.max_batch_seqs = max_batch_seqs
         self.max_blocks_cap = (self.max_model_len + block_size - 1) // block_size + 1
-        self.nominal_ctx = min(self.max_model_len, 1024)
+        # Decode graphs are captured per (batch bucket, context class): the number of KV splits
+        # and prefix pieces is a launch-time constant, and the right one depends on how long the
+        # contexts of the step are. Classes are powers of two from 256 keys up.
+        self.ctx_classes = [c for c in (256, 512, 1024, 2048, 4096, 8192, 16384, 32768, 65536, 131072)
+                            if c < 2 * self.max_model_len] or [256]
         self.max_decision = max_decision
         self.max_group_rows = max_group_rows
         # Decode steps are captured into hipGraphs by default. Steps that contain collectives
@@ -548,14 +554,18 @@ class Engine:
                             ctx_lens=self._dev(plan.context_lens), cu_q=self._dev(cu), max_q_len=int(np.diff(cu).max()))
         hidden = m.forward(tok, self._dev(plan.positions), self._dev(plan.slot_mapping), meta, self.kv)
         req_ids = plan.request_ids
-        # Embed requests: accumulate the sum of this chunk's final hidden states.
-        for i, rid in enumerate(req_ids[:n_seq - n_riders]):
-            st = self._reqs[int(rid)]
-            if st.kind == core.RequestKind.Embed:
-                rows = hidden[int(cu[i]):int(cu[i + 1])].float()
-                s = rows.sum(0)
-                st.embed_sum = s if st.embed_sum is None else st.embed_sum + s
-                st.embed_count += rows.shape[0]
+        # Embed requests: one pooling launch over the chunks of all of them in this step (fp32
+        # sums of the final hidden states per chunk); a prompt cut into several chunks adds its
+        # chunk sums up, the mean and the L2 normalisation happen when the request finishes.
+        emb = [i for i, rid in enumerate(req_ids[:n_seq - n_riders])
+               if self._reqs[int(rid)].kind == core.RequestKind.Embed]
+        if emb:
+            sums = ops.embed_pool_ranges(hidden, self._dev(np.array([cu[i] for i in emb], dtype=np.int32)),
+                                         self._dev(np.array([cu[i + 1] for i in emb], dtype=np.int32)), mode=2)
+            for j, i in enumerate(emb):
+                st = self._reqs[int(req_ids[i])]
+                st.embed_sum = sums[j] if st.embed_sum is None else st.embed_sum + sums[j]
+                st.embed_count += int(cu[i + 1] - cu[i])
         toks = lps = logits = None
         n_last = len(plan.last_rows)
         if n_last or n_riders:
@@ -653,10 +663,12 @@ class Engine:
         with_prefix = bool(len(gshared)) and bool(((gshared > 0) & (gcount > 1)).any()) and \
             int(gcount.max()) <= self.max_group_rows
         bucket = self._bucket(B) if (self.use_graphs or self.piecewise) else B
-        key = (bucket, with_prefix)
+        max_ctx = int(plan.context_lens.max())
+        ctx_class = next((c for c in self.ctx_classes if c >= max_ctx), self.ctx_classes[-1])
+        key = (bucket, with_prefix, ctx_class)
         g = self._graphs.get(key)
         if g is None:
-            g = _DecodeGraph(self, bucket, with_prefix)
+            g = _DecodeGraph(self, bucket, with_prefix, ctx_class)
             if not self.use_graphs:
                 g.nsplit = 1 if self.device.type != "cuda" else g.nsplit
             self._graphs[key] = g
@@ -807,8 +819,7 @@ class Engine:
             if st.kind == core.RequestKind.Score:
                 out.scores = st.scores
             if st.kind == core.RequestKind.Embed and st.embed_sum is not None:
-                v = (st.embed_sum / max(1, st.embed_count))
-                out.embedding = (v / v.norm().clamp_min(1e-12)).cpu().numpy()
+                out.embedding = ops.l2_normalize(st.embed_sum.view(1, -1))[0].cpu().numpy()
             self._done[f.request_id] = out
             self.metrics.inc("requests.finished")
             self.metrics.observe("request.latency_ms", (out.finished_at - out.submitted_at) * 1e3)

@@ -11,7 +11,9 @@ from __future__ import annotations
 import json
 from dataclasses import dataclass, replace
 from pathlib import Path
-from typing import Dict, Optional
+from typing import Dict, Optional, Tuple
+
+SUPPORTED_MODEL_TYPES = ("llama", "qwen2", "mistral", "mixtral")
 
 
 @dataclass(frozen=True)
@@ -33,6 +35,12 @@ class ModelConfig:
     num_experts: int = 0             # 0 = dense MLP
     experts_per_tok: int = 0
     model_type: str = "llama"
+    # checkpoint's rope_scaling as sorted (key, value) pairs (hashable); see ops.reference.rope_inv_freq
+    rope_scaling: Optional[Tuple[Tuple[str, object], ...]] = None
+
+    @property
+    def rope_scaling_dict(self) -> Optional[dict]:
+        return dict(self.rope_scaling) if self.rope_scaling else None
 
     @property
     def is_moe(self) -> bool:
@@ -111,6 +119,18 @@ def from_hf_config(path: str) -> ModelConfig:
         p = p / "config.json"
     c = json.loads(p.read_text())
     mt = c.get("model_type", "llama")
+    if mt not in SUPPORTED_MODEL_TYPES:
+        raise ValueError(f"{p}: model_type {mt!r} is not supported (supported: {', '.join(SUPPORTED_MODEL_TYPES)})")
+    scaling = c.get("rope_scaling") or None
+    if scaling is None and isinstance(c.get("rope_parameters"), dict):
+        rp = c["rope_parameters"]
+        if rp.get("rope_type", "default") not in (None, "default"):
+            scaling = {k: v for k, v in rp.items() if k != "rope_theta"}
+    if scaling is not None:
+        from ..ops.reference import rope_inv_freq
+
+        rope_inv_freq(2, 10000.0, dict(scaling))      # raises on a rule the engine does not implement
+        scaling = tuple(sorted((str(k), v) for k, v in scaling.items() if not isinstance(v, (list, dict))))
     heads = c["num_attention_heads"]
     head_dim = c.get("head_dim") or c["hidden_size"] // heads
     sw = c.get("sliding_window") or 0
@@ -134,6 +154,7 @@ def from_hf_config(path: str) -> ModelConfig:
         num_experts=int(c.get("num_local_experts", 0)),
         experts_per_tok=int(c.get("num_experts_per_tok", 0)),
         model_type=mt,
+        rope_scaling=scaling,
     )
     cfg.validate()
     return cfg
@@ -168,4 +189,6 @@ def to_hf_config(cfg: ModelConfig) -> dict:
         d["num_experts_per_tok"] = cfg.experts_per_tok
     if cfg.model_type == "qwen2":
         d["use_sliding_window"] = False
+    if cfg.rope_scaling:
+        d["rope_scaling"] = dict(cfg.rope_scaling)
     return d

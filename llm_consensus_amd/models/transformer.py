@@ -109,7 +109,7 @@ class TransformerModel:
         self.final_norm: Optional[torch.Tensor] = None
         self.lm_head: Optional[ops.LinearWeight] = None
         self.layers: List[LayerWeights] = []
-        cos, sin = ref.rope_tables(cfg.head_dim, cfg.max_position, cfg.rope_theta)
+        cos, sin = ref.rope_tables(cfg.head_dim, cfg.max_position, cfg.rope_theta, scaling=cfg.rope_scaling_dict)
         self.cos_t, self.sin_t = cos.to(self.device), sin.to(self.device)
         self.scale = cfg.head_dim ** -0.5
 

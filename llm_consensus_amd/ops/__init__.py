@@ -338,13 +338,35 @@ def add(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
 
 
 def embed_pool(hidden: torch.Tensor, cu: torch.Tensor, mode: int = 0) -> torch.Tensor:
+    """Pooled, L2-normalised embeddings of the sequences whose rows are [cu[s], cu[s+1])
+    (mode 0: mean, 1: last row)."""
+    return embed_pool_ranges(hidden, cu[:-1], cu[1:], mode)
+
+
+def embed_pool_ranges(hidden: torch.Tensor, begin: torch.Tensor, end: torch.Tensor, mode: int = 0) -> torch.Tensor:
+    """As ``embed_pool`` over explicit row ranges; mode 2 returns the plain fp32 row sums
+    (chunked prompts add their chunk sums and normalise at the end with ``l2_normalize``)."""
     if not hidden.is_cuda:
-        return ref.embed_pool(hidden, cu, mode)
+        if mode == 2:
+            return torch.stack([hidden[int(b):int(e)].float().sum(0) for b, e in zip(begin, end)])
+        return torch.stack([ref.embed_pool(hidden, torch.tensor([int(b), int(e)]), mode)[0] for b, e in zip(begin, end)])
     h = _hip()
-    n = cu.numel() - 1
+    n = begin.numel()
+    begin, end = begin.contiguous(), end.contiguous()
     out = torch.empty(n, hidden.shape[1], dtype=torch.float32, device=hidden.device)
-    h.call("lc_embed_pool", hidden.data_ptr(), cu.data_ptr(), out.data_ptr(), n, hidden.shape[1], mode)
+    h.call("lc_embed_pool", hidden.data_ptr(), begin.data_ptr(), end.data_ptr(), out.data_ptr(), n, hidden.shape[1], mode)
     return out
+
+
+def l2_normalize(x: torch.Tensor) -> torch.Tensor:
+    """Rows of fp32 ``x`` scaled to unit length (zero rows stay zero)."""
+    if not x.is_cuda:
+        return x / x.norm(dim=-1, keepdim=True).clamp_min(1e-30)
+    h = _hip()
+    x = x.contiguous()
+    y = torch.empty_like(x)
+    h.call("lc_l2_normalize", x.data_ptr(), y.data_ptr(), x.shape[0], x.shape[1])
+    return y
 
 
 # ---------------------------------------------------------------------------- rope + cache

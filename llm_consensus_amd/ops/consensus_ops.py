@@ -8,27 +8,33 @@ from .._native import core
 from . import hip as h
 
 
-def majority_vote_device(votes: np.ndarray, num_classes: int, tie, device):
+_TIE_CODE = {core.TieBreak.LowestClass: 0, core.TieBreak.FirstVoter: 1, core.TieBreak.HighestWeight: 2}
+
+
+def majority_vote_device(votes: np.ndarray, num_classes: int, tie, device, weights=None):
     from ..consensus.reducers import VoteBatch, majority_vote_batch
 
-    if num_classes > 64 or tie == core.TieBreak.HighestWeight:
-        return majority_vote_batch(votes, num_classes, tie, device=None)  # outside the kernel's envelope
+    if num_classes > 64:
+        return majority_vote_batch(votes, num_classes, tie, device=None, weights=weights)  # kernel: one lane per class
     R, N = votes.shape
     v = torch.from_numpy(votes).to(device)
+    w = torch.from_numpy(np.ascontiguousarray(weights, dtype=np.float32)).to(device) if weights is not None else None
     winner = torch.empty(R, dtype=torch.int32, device=device)
     count = torch.empty_like(winner)
     valid = torch.empty_like(winner)
     unan = torch.empty_like(winner)
     agree = torch.empty(R, dtype=torch.float32, device=device)
-    h.call("lc_majority_vote", v.data_ptr(), R, N, num_classes, 1 if tie == core.TieBreak.FirstVoter else 0,
-           winner.data_ptr(), count.data_ptr(), valid.data_ptr(), agree.data_ptr(), unan.data_ptr())
+    h.call("lc_majority_vote", v.data_ptr(), R, N, num_classes, _TIE_CODE[tie],
+           winner.data_ptr(), count.data_ptr(), valid.data_ptr(), agree.data_ptr(), unan.data_ptr(), h.ptr(w))
     return VoteBatch(winner.cpu().numpy(), count.cpu().numpy(), valid.cpu().numpy(), agree.cpu().numpy(),
                      unan.cpu().numpy().astype(bool))
 
 
-def majority_vote_tensors(votes: torch.Tensor, num_classes: int, tie_first_voter: bool = False):
-    """Device-resident variant (votes int32 [R, N] already on the GPU); returns device tensors
-    (winner, count, valid, agreement, unanimous) without a host round trip."""
+def majority_vote_tensors(votes: torch.Tensor, num_classes: int, tie_first_voter: bool = False,
+                          weights: "torch.Tensor | None" = None):
+    """Device-resident variant (votes int32 [R, N] already on the GPU, weights float32 [N] or
+    None); returns device tensors (winner, count, valid, agreement, unanimous) without a host
+    round trip."""
     R, N = votes.shape
     dev = votes.device
     winner = torch.empty(R, dtype=torch.int32, device=dev)
@@ -37,7 +43,7 @@ def majority_vote_tensors(votes: torch.Tensor, num_classes: int, tie_first_voter
     unan = torch.empty_like(winner)
     agree = torch.empty(R, dtype=torch.float32, device=dev)
     h.call("lc_majority_vote", votes.data_ptr(), R, N, num_classes, 1 if tie_first_voter else 0, winner.data_ptr(),
-           count.data_ptr(), valid.data_ptr(), agree.data_ptr(), unan.data_ptr())
+           count.data_ptr(), valid.data_ptr(), agree.data_ptr(), unan.data_ptr(), h.ptr(weights))
     return winner, count, valid, agree, unan
 
 

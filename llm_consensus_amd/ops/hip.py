@@ -22,7 +22,8 @@ _SIGNATURES = {
     "lc_swiglu": [_P, _P, _I, _I, _P],
     "lc_add": [_P, _P, _P, _L, _P],
     "lc_copy_blocks": [_P, _P, _P, _I, _L, _L, _I, _P],
-    "lc_embed_pool": [_P, _P, _P, _I, _I, _I, _P],
+    "lc_embed_pool": [_P, _P, _P, _P, _I, _I, _I, _P],
+    "lc_l2_normalize": [_P, _P, _I, _I, _P],
     "lc_gemm_tile": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "lc_gemm256": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "lc_gemm_panel": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P],
@@ -41,7 +42,7 @@ _SIGNATURES = {
     "lc_fill_f32": [_P, _F, _L, _P],
     "lc_sample": [_P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P],
     "lc_logprob_gather": [_P, _I, _I, _P, _P, _I, _I, _P, _I, _P],
-    "lc_majority_vote": [_P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P],
+    "lc_majority_vote": [_P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P],
     "lc_cosine_medoid": [_P, _I, _I, _I, _L, _P, _P, _P, _P],
     "lc_judge_reduce": [_P, _I, _I, _I, _P, _P, _P, _P],
     "lc_answer_extract": [_P, _P, _I, _I, _P, _I, _P, _I, _I, _P, _P],

@@ -56,8 +56,37 @@ def linear(x: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor] = None
 
 
 # ------------------------------------------------------------------ RoPE + KV write
-def rope_tables(head_dim: int, max_pos: int, theta: float, device="cpu") -> Tuple[torch.Tensor, torch.Tensor]:
+def rope_inv_freq(head_dim: int, theta: float, scaling: Optional[dict] = None) -> torch.Tensor:
+    """Rotary inverse frequencies (float64, [head_dim/2]). ``scaling`` is a checkpoint's
+    ``rope_scaling`` dict: ``llama3`` (Llama-3.1/3.2: wavelengths beyond the original context
+    divided by ``factor``, a smooth blend between ``low_freq_factor`` and ``high_freq_factor``),
+    ``linear`` (every frequency divided by ``factor``) or none/``default``. Anything else raises:
+    a silently ignored scaling rule changes the logits at every position."""
+    import math
+
     inv = 1.0 / (theta ** (torch.arange(0, head_dim, 2, dtype=torch.float64) / head_dim))
+    if not scaling:
+        return inv
+    kind = scaling.get("rope_type", scaling.get("type", "default"))
+    if kind in (None, "default"):
+        return inv
+    if kind == "linear":
+        return inv / float(scaling["factor"])
+    if kind == "llama3":
+        factor = float(scaling["factor"])
+        lo, hi = float(scaling.get("low_freq_factor", 1.0)), float(scaling.get("high_freq_factor", 4.0))
+        old = float(scaling["original_max_position_embeddings"])
+        wavelen = 2 * math.pi / inv
+        smooth = ((old / wavelen - lo) / (hi - lo)).clamp(0.0, 1.0)
+        blended = (1 - smooth) * inv / factor + smooth * inv
+        out = torch.where(wavelen > old / lo, inv / factor, torch.where(wavelen < old / hi, inv, blended))
+        return out
+    raise ValueError(f"rope_scaling type {kind!r} is not supported (supported: default, linear, llama3)")
+
+
+def rope_tables(head_dim: int, max_pos: int, theta: float, device="cpu",
+                scaling: Optional[dict] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+    inv = rope_inv_freq(head_dim, theta, scaling)
     ang = torch.arange(max_pos, dtype=torch.float64)[:, None] * inv[None, :]
     return ang.cos().float().to(device), ang.sin().float().to(device)
 

@@ -89,7 +89,9 @@ class HFTokenizer(Tokenizer):
         f = p / "tokenizer.json" if p.is_dir() else p
         self._t = _Tok.from_file(str(f))
         self.vocab_size = self._t.get_vocab_size()
-        self.bos_id = self._find("<|begin_of_text|>", "<s>", "<|im_start|>")
+        # Qwen checkpoints have no BOS: <|im_start|> opens a chat turn and is part of the chat
+        # format, not a sequence prefix, so it is not a candidate here.
+        self.bos_id = self._find("<|begin_of_text|>", "<s>")
         ends = [self._t.token_to_id(n) for n in ("<|end_of_text|>", "<|eot_id|>", "</s>", "<|im_end|>", "<|endoftext|>")]
         ends = [i for i in ends if i is not None]
         self.eos_id = ends[0] if ends else None

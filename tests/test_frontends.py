@@ -99,6 +99,27 @@ def test_cli_questions_file(tmp_path, capsys):
     assert len(lines) == 2 and all(x["answer"] in "ABCD" for x in lines)
 
 
+def test_cli_warns_when_answers_come_from_random_weights(tmp_path, capsys):
+    """The reference refuses to start without a usable backend (main.rs:354-357); a model
+    with no checkpoint path still runs here, but not silently."""
+    qf = tmp_path / "q.txt"
+    qf.write_text("one? A) x B) y C) z D) w\n")
+    cli.main(["--config", str(CONFIGS / "plumbing_tiny.toml"), "--questions", str(qf), "--device", "cpu"])
+    err = capsys.readouterr().err
+    assert "RANDOM-INIT" in err and "m0" in err
+
+
+def test_removed_config_keys_are_rejected():
+    from llm_consensus_amd.config import config_from_dict
+
+    with pytest.raises(ValueError, match="proposer_policy"):
+        config_from_dict({"proposer_policy": "all"})
+    with pytest.raises(ValueError, match="unknown ModelSpec keys"):
+        config_from_dict({"models": {"default": {"dtype": "fp8"}}})
+    with pytest.raises(ValueError, match="admission"):
+        config_from_dict({"models": {"default": {"admission": "greedy"}}})
+
+
 # ---------------------------------------------------------------- HTTP endpoint
 def _post(port, path, body, timeout=120):
     req = urllib.request.Request(f"http://127.0.0.1:{port}{path}", json.dumps(body).encode(),
@@ -202,7 +223,8 @@ def test_placement_70b_judge_spread():
     assert plan.feasible
     rep = plan.replicas[0]
     judge = next(m for m in rep.members if m.name == "judge")
-    assert len(judge.devices) == 4
+    assert len(judge.devices) == 4 and plan.gpus_per_replica == 8      # 4 proposers on a GPU each + TP=4 judge
+    assert len({d for m in rep.members for d in m.devices}) == 8
     for r in judge.devices:
         assert assignment_for_rank(plan, cfg, r).models["judge"] == list(judge.devices)
 

@@ -180,6 +180,14 @@ def test_embed_swiglu_add_pool():
     cu = torch.tensor([0, 5, 5, 20], dtype=torch.int32)
     for mode in (0, 1):
         assert rel_err(ops.embed_pool(hid.to(DEV), cu.to(DEV), mode), ref.embed_pool(hid, cu, mode)) < 1e-5
+    # explicit row ranges, raw fp32 sums (chunked prompts), then the separate normalisation
+    hid = bf(rand(300, 4096, seed=3))
+    b = torch.tensor([0, 17, 290], dtype=torch.int32)
+    e = torch.tensor([17, 290, 300], dtype=torch.int32)
+    sums = ops.embed_pool_ranges(hid.to(DEV), b.to(DEV), e.to(DEV), mode=2)
+    want = torch.stack([hid[int(x):int(y)].float().sum(0) for x, y in zip(b, e)])
+    assert rel_err(sums, want) < 1e-5
+    assert rel_err(ops.l2_normalize(sums), want / want.norm(dim=-1, keepdim=True)) < 1e-5
 
 
 # ------------------------------------------------------------------ rope + cache + attention
@@ -317,6 +325,43 @@ def test_attn_decode_matches_reference(Hq, Hkv, Dh, BS, nsplit):
     assert rel_err(got, want) < 1e-2
 
 
+@pytest.mark.parametrize("Hq,Hkv,Dh,BS", [(8, 2, 128, 16), (4, 1, 128, 8), (14, 2, 64, 16)])
+def test_attention_over_more_than_64_blocks(Hq, Hkv, Dh, BS):
+    """Contexts longer than 64 blocks: each lane of the attention kernels keeps 64 block-table
+    entries in registers and reloads them after every 64 blocks. Decode (1 and several splits),
+    chunked prefill and the shared-prefix pass all walk past that boundary here."""
+    lens = [70 * BS + 3, 1100 if BS == 16 else 133 * BS + 1, 5]
+    kc, vc, tables, qkvs, _ = build_paged_context(lens, Hq, Hkv, Dh, BS, seed=21, device=DEV)
+    scale = Dh ** -0.5
+    ctx = torch.tensor(lens, dtype=torch.int32)
+    rows = torch.stack([qkvs[s][-1] for s in range(len(lens))])
+    want = ref.attn_decode(rows[:, : Hq * Dh], kc.cpu(), vc.cpu(), tables.cpu(), ctx, Hq, Hkv, Dh, scale)
+    for nsplit in (1, 2, 8):
+        got = ops.attn_decode(rows.to(DEV), kc, vc, tables, ctx.to(DEV), Hq, Hkv, Dh, scale, nsplit=nsplit)
+        assert rel_err(got, want) < 1e-2, nsplit
+    # prefill: the last 40 tokens of each long sequence attend over the whole paged context
+    q_lens = [40, 40, 5]
+    prow = torch.cat([qkvs[s][lens[s] - q_lens[s]:] for s in range(len(lens))])
+    cu = torch.tensor([0] + list(np.cumsum(q_lens)), dtype=torch.int32)
+    got = ops.attn_prefill(prow.to(DEV), kc, vc, tables, cu.to(DEV), ctx.to(DEV), max(q_lens), Hq, Hkv, Dh, scale)
+    wantp = ref.attn_prefill(prow[:, : Hq * Dh], kc.cpu(), vc.cpu(), tables.cpu(), cu, ctx, Hq, Hkv, Dh, scale)
+    assert rel_err(got, wantp) < 1e-2
+    # shared prefix of 68 blocks between two rows that continue the first sequence
+    t2 = tables.clone()
+    lens2 = [lens[0], lens[0] - 2]
+    rows2 = torch.stack([qkvs[0][-1], qkvs[0][-3]])
+    tb = torch.stack([t2[0], t2[0]])
+    ctx2 = torch.tensor(lens2, dtype=torch.int32)
+    want2 = ref.attn_decode(rows2[:, : Hq * Dh], kc.cpu(), vc.cpu(), tb.cpu(), ctx2, Hq, Hkv, Dh, scale)
+    groups = (torch.tensor([0], dtype=torch.int32, device=DEV), torch.tensor([2], dtype=torch.int32, device=DEV),
+              torch.tensor([68], dtype=torch.int32, device=DEV))
+    kvb = torch.full((2,), 68 * BS, dtype=torch.int32, device=DEV)
+    for psplit in (1, 4, 8):
+        got2 = ops.attn_decode(rows2.to(DEV), kc, vc, tb.contiguous(), ctx2.to(DEV), Hq, Hkv, Dh, scale, nsplit=1,
+                               groups=groups, kv_begin=kvb, max_group_rows=2, prefix_splits=psplit)
+        assert rel_err(got2, want2) < 1e-2, psplit
+
+
 @pytest.mark.parametrize("Hq,Hkv,Dh,BS,K", [(8, 2, 128, 64, 16), (14, 2, 64, 16, 5), (8, 1, 128, 32, 3)])
 def test_shared_prefix_decode_equals_unshared(Hq, Hkv, Dh, BS, K):
     """K chains forked from one prompt: prefix pass + per-chain suffix pass + merge must
@@ -424,6 +469,13 @@ def test_majority_vote_kernel_matches_host():
             for f in ("winner", "count", "valid", "unanimous"):
                 assert np.array_equal(getattr(host, f), getattr(dev, f)), (N, C, f)
             assert np.allclose(host.agreement, dev.agreement)
+        # member weights: weighted plurality (tie 0/1) and count-then-weight (HighestWeight)
+        w = rng.choice([0.5, 1.0, 1.5, 2.0, 3.0], size=N).astype(np.float32)
+        for tie in (core.TieBreak.LowestClass, core.TieBreak.FirstVoter, core.TieBreak.HighestWeight):
+            host = reducers.majority_vote_batch(votes, C, tie, weights=w)
+            dev = reducers.majority_vote_batch(votes, C, tie, device=DEV, weights=w)
+            for f in ("winner", "count", "valid", "unanimous"):
+                assert np.array_equal(getattr(host, f), getattr(dev, f)), (N, C, f, tie)
 
 
 def test_cosine_medoid_and_judge_kernels_match_host():

@@ -78,3 +78,53 @@ def test_load_model_on_gpu_equals_cpu_load(ckpt):
     assert torch.equal(g.layers[1].ln2.cpu(), c.layers[1].ln2)
     tok = torch.tensor([1, 2, 3], dtype=torch.int32)
     assert g.lm_head.n == c.lm_head.n and g.layers[0].gate_up.k == c.layers[0].gate_up.k
+
+
+def test_rope_scaling_llama3_matches_closed_form_and_unknown_rules_raise(tmp_path):
+    """Llama-3.1-style rope_scaling: wavelengths beyond original_max/low_freq_factor are divided
+    by `factor`, those below original_max/high_freq_factor are kept, the band between blends
+    linearly in original_max/wavelength. Unknown rules and model types are refused."""
+    import json
+    import math
+
+    import pytest
+    import torch
+
+    from llm_consensus_amd.models.config import from_hf_config, get_preset, to_hf_config
+    from llm_consensus_amd.ops.reference import rope_inv_freq, rope_tables
+
+    sc = {"rope_type": "llama3", "factor": 8.0, "low_freq_factor": 1.0, "high_freq_factor": 4.0,
+          "original_max_position_embeddings": 8192}
+    theta, Dh = 5e5, 128
+    got = rope_inv_freq(Dh, theta, sc)
+    want = []
+    for i in range(0, Dh, 2):
+        f = 1.0 / theta ** (i / Dh)
+        wl = 2 * math.pi / f
+        if wl < 8192 / 4.0:
+            want.append(f)
+        elif wl > 8192 / 1.0:
+            want.append(f / 8.0)
+        else:
+            sm = (8192 / wl - 1.0) / (4.0 - 1.0)
+            want.append((1 - sm) * f / 8.0 + sm * f)
+    assert torch.allclose(got, torch.tensor(want, dtype=torch.float64), rtol=1e-12)
+    assert (got[:20] == rope_inv_freq(Dh, theta)[:20]).all() and got[-1] == rope_inv_freq(Dh, theta)[-1] / 8.0
+    cos, _ = rope_tables(Dh, 64, theta, scaling=sc)
+    assert abs(float(cos[63, -1]) - math.cos(63 * want[-1])) < 1e-6
+    assert torch.allclose(rope_inv_freq(Dh, theta, {"type": "linear", "factor": 2.0}), rope_inv_freq(Dh, theta) / 2)
+
+    hf = to_hf_config(get_preset("tiny-llama"))
+    hf["rope_scaling"] = sc
+    (tmp_path / "config.json").write_text(json.dumps(hf))
+    cfg = from_hf_config(str(tmp_path))
+    assert cfg.rope_scaling_dict["factor"] == 8.0 and to_hf_config(cfg)["rope_scaling"]["rope_type"] == "llama3"
+    hf["rope_scaling"] = {"rope_type": "yarn", "factor": 4.0}
+    (tmp_path / "config.json").write_text(json.dumps(hf))
+    with pytest.raises(ValueError, match="yarn"):
+        from_hf_config(str(tmp_path))
+    hf.pop("rope_scaling")
+    hf["model_type"] = "gpt_neox"
+    (tmp_path / "config.json").write_text(json.dumps(hf))
+    with pytest.raises(ValueError, match="gpt_neox"):
+        from_hf_config(str(tmp_path))

@@ -1,3 +1,4 @@
+import pytest
 import numpy as np
 from hypothesis import given, settings, strategies as st
 
@@ -65,3 +66,34 @@ def test_answer_extract_host():
     got = reducers.answer_extract(ids, lens, marker, choices, window=3)
     assert got.tolist() == [1, 3, -1, -1, -1]
     assert reducers.answer_extract(ids, lens, [], choices).tolist() == [1, 3, 3, 1, -1]
+
+
+def test_member_weights_flip_a_two_to_one_vote():
+    """MemberConfig.weight reaches the reducer: one heavy member outvotes two light ones; with
+    tie_break = highest_weight the weights only decide ties in count."""
+    from llm_consensus_amd._native import core
+    from llm_consensus_amd.consensus import reducers
+    from llm_consensus_amd.consensus.backend import GenParams, ScriptedBackend
+    from llm_consensus_amd.consensus.members import Member
+    from llm_consensus_amd.consensus.strategies import MajorityVote
+
+    votes = np.array([[1, 1, 2], [0, 3, -1]], dtype=np.int32)
+    plain = reducers.majority_vote_batch(votes, 4)
+    assert plain.winner.tolist() == [1, 0]
+    heavy = reducers.majority_vote_batch(votes, 4, weights=np.array([1.0, 1.0, 2.5], dtype=np.float32))
+    assert heavy.winner.tolist() == [2, 0] and heavy.count.tolist() == [1, 1]
+    tie = reducers.majority_vote_batch(votes, 4, core.TieBreak.HighestWeight,
+                                       weights=np.array([1.0, 3.0, 2.5], dtype=np.float32))
+    assert tie.winner.tolist() == [1, 3]          # row 0: count decides; row 1: 1-1 tie goes to the heavier voter
+    with pytest.raises(ValueError):
+        reducers.majority_vote_batch(votes, 4, weights=np.ones(2, dtype=np.float32))
+
+    personas = core.default_personas()
+    answers = ["Answer: B", "Answer: B", "Answer: C"]
+    members = [Member(personas[i], ScriptedBackend({"propose": [a]}, name=f"m{i}"), params=GenParams(max_new_tokens=4),
+                      weight=w) for i, (a, w) in enumerate(zip(answers, (1.0, 1.0, 2.5)))]
+    res = MajorityVote(members).ask("Which? A) a B) b C) c D) d")
+    assert res.answer == "C"
+    for m in members:
+        m.weight = 1.0
+    assert MajorityVote(members).ask("Which? A) a B) b C) c D) d").answer == "B"

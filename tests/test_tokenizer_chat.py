@@ -69,3 +69,24 @@ def test_backend_applies_the_format_and_stops_at_any_turn_end(llama3_like_tokeni
     assert h2.result().prompt_tokens > h1.result().prompt_tokens + 8    # turn markers were added
     with pytest.raises(ValueError):
         EngineBackend(eng, llama3_like_tokenizer, chat_format="bogus")
+
+
+def test_qwen_style_vocabulary_gets_no_bos(tmp_path):
+    """Qwen checkpoints have no BOS token: <|im_start|> opens a chat turn and must not be
+    prepended to every prompt as if it were one."""
+    from tokenizers import Tokenizer, decoders, models, pre_tokenizers, trainers
+
+    tok = Tokenizer(models.BPE(unk_token=None))
+    tok.pre_tokenizer = pre_tokenizers.ByteLevel(add_prefix_space=False)
+    tok.decoder = decoders.ByteLevel()
+    trainer = trainers.BpeTrainer(vocab_size=280, special_tokens=["<|endoftext|>", "<|im_start|>", "<|im_end|>"],
+                                  initial_alphabet=pre_tokenizers.ByteLevel.alphabet())
+    tok.train_from_iterator(["user assistant system answer"] * 4, trainer)
+    tok.save(str(tmp_path / "tokenizer.json"))
+    t = HFTokenizer(str(tmp_path))
+    assert t.bos_id is None
+    im_start = t._t.token_to_id("<|im_start|>")
+    assert t.encode("answer")[0] != im_start
+    ids = t.encode(apply_chat_format("chatml", "answer"))
+    assert ids[0] == im_start and ids.count(im_start) == 2            # only the two the format wrote
+    assert t.eos_id == t._t.token_to_id("<|im_end|>") and t._t.token_to_id("<|endoftext|>") in t.stop_ids
