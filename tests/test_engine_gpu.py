@@ -106,7 +106,7 @@ def test_forked_chains_use_shared_prefix_and_match_independent(name, bs):
         # one prompt per prefill step, as in the forked run: GEMM tile paths (and so the rounding of
         # the K-sums) depend on the number of rows, and bit-equality is only claimed for equal shapes
         eng = Engine(gpu, num_kv_blocks=512, block_size=bs, use_graphs=False, enable_prefix_cache=False,
-                     max_prefill_tokens=len(prompt))
+                     max_prefill_tokens=len(prompt), mix_decode=False)   # no riders: same GEMM shapes as the forked run
         rids = [eng.submit(prompt, params=params(n_new, seed=500 + k, temperature=temp, top_p=0.95)) for k in range(K)]
         eng.run_until_done()
         return [eng.pop_result(r) for r in rids]
@@ -128,7 +128,10 @@ def test_forked_chains_use_shared_prefix_and_match_independent(name, bs):
     f_pref, _ = forked(0.8, True, 16)
     mean_ind = np.mean([r.cum_logprobs[0] for r in ind])
     assert abs(np.mean(f_pref.cum_logprobs) - mean_ind) < 0.15 * abs(mean_ind)
-    assert sum(a.token_ids[0] == b for a, b in zip(ind, f_pref.token_ids)) >= 2
+    # every chain's first token comes from the shared prefill (same logits, same RNG stream); later
+    # tokens may part ways where rounding moves a sample across a CDF boundary
+    assert [a.token_ids[0][0] for a in ind] == [b[0] for b in f_pref.token_ids]
+    assert sum(a.token_ids[0][:3] == b[:3] for a, b in zip(ind, f_pref.token_ids)) >= K // 2
 
 
 def test_strategies_end_to_end_on_gpu_backend():
