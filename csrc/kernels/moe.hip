@@ -167,7 +167,132 @@ __global__ void moe_combine_kernel(const bf16_t* __restrict__ Y, const int32_t* 
   }
 }
 
+// ---- expert-parallel exchange (fixed capacity, no host round trip) -------------------------
+// ep ranks, `per` experts each. A rank routes its own token slice, sorts the (token, k) pairs
+// by expert (moe_permute_kernel) and ships the rows of experts [r*per, (r+1)*per) to rank r.
+// Every (source, destination) pair owns `cap` rows of a [ep, cap, d] buffer, so the exchange
+// is an all-to-all with equal splits whatever the routing is; how many of the rows are real
+// travels beside them as per-expert counts.
+//
+// ep_pack: one wave per send row. Row (r, j), j < rows routed to rank r, is a copy of the
+// token row of the j-th pair of that destination (pairs of one destination are contiguous
+// in expert-sorted order). send_counts[r*per + e] = pairs for expert r*per + e.
+// slot_back[a] = row of the RETURNED buffer (same [ep, cap, d] layout) that holds the expert
+// output of pair a: the combine kernel reads it through this map.
+__global__ void ep_pack_kernel(const bf16_t* __restrict__ x, const int32_t* __restrict__ sorted_src,
+                               const int32_t* __restrict__ offsets, const int32_t* __restrict__ slot_of,
+                               int per, int ep, int cap, int A, int d, bf16_t* __restrict__ send,
+                               int32_t* __restrict__ send_counts, int32_t* __restrict__ slot_back) {
+  const int w = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  const int gtid = blockIdx.x * blockDim.x + threadIdx.x;
+  if (gtid < ep * per) send_counts[gtid] = offsets[gtid + 1] - offsets[gtid];
+  if (gtid < A) {
+    const int slot = slot_of[gtid];
+    int r = 0;
+    while (r + 1 < ep && slot >= offsets[(r + 1) * per]) ++r;
+    slot_back[gtid] = r * cap + (slot - offsets[r * per]);
+  }
+  if (w >= ep * cap) return;
+  const int r = w / cap, j = w - r * cap;
+  const int start = offsets[r * per], cnt = offsets[(r + 1) * per] - start;
+  if (j >= cnt) return;
+  const bf16_t* src = x + static_cast<size_t>(sorted_src[start + j]) * d;
+  bf16_t* dst = send + static_cast<size_t>(w) * d;
+  for (int c = lane * 8; c < d; c += 64 * 8)
+    *reinterpret_cast<bf16x8*>(dst + c) = *reinterpret_cast<const bf16x8*>(src + c);
+}
+
+// ep_recv_index: single block. recv_counts[s*per + e] = rows source s sent for local expert e;
+// they sit in the receive buffer at rows s*cap + (sum of that source's counts for experts < e)
+// onwards. Builds what the grouped GEMM wants: offsets_local[per+1] over the experts and, for
+// every position of the expert-sorted order, the receive-buffer row it reads (row_index).
+// Positions beyond the last real row point at row 0.
+__global__ __launch_bounds__(256) void ep_recv_index_kernel(const int32_t* __restrict__ recv_counts, int ep,
+                                                            int per, int cap, int32_t* __restrict__ row_index,
+                                                            int32_t* __restrict__ offsets_local) {
+  __shared__ int seg_base[kMaxExperts * 64];   // [e][s]: first sorted position of source s's rows for expert e
+  __shared__ int src_cum[64 * (kMaxExperts + 1)];  // [s][e]: rows of source s for experts < e
+  __shared__ int total;
+  if (threadIdx.x == 0) {
+    int run = 0;
+    for (int e = 0; e < per; ++e) {
+      offsets_local[e] = run;
+      for (int s = 0; s < ep; ++s) {
+        seg_base[e * ep + s] = run;
+        run += recv_counts[s * per + e];
+      }
+    }
+    offsets_local[per] = run;
+    total = run;
+    for (int s = 0; s < ep; ++s) {
+      int c = 0;
+      for (int e = 0; e < per; ++e) {
+        src_cum[s * (per + 1) + e] = c;
+        c += recv_counts[s * per + e];
+      }
+      src_cum[s * (per + 1) + per] = c;
+    }
+  }
+  __syncthreads();
+  const int rows = ep * cap;
+  for (int p = total + threadIdx.x; p < rows; p += blockDim.x) row_index[p] = 0;
+  for (int w = threadIdx.x; w < rows; w += blockDim.x) {
+    const int s = w / cap, j = w - s * cap;
+    const int* cum = src_cum + s * (per + 1);
+    if (j >= cum[per]) continue;
+    int e = 0;
+    while (e + 1 < per && j >= cum[e + 1]) ++e;
+    row_index[seg_base[e * ep + s] + (j - cum[e])] = w;
+  }
+}
+
+// out[row_index[p], :] = y[p, :] for p < *total (one wave per row).
+__global__ void scatter_rows_kernel(const bf16_t* __restrict__ y, const int32_t* __restrict__ row_index,
+                                    const int32_t* __restrict__ total, int cap_rows, int d,
+                                    bf16_t* __restrict__ out) {
+  const int p = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (p >= cap_rows || p >= *total) return;
+  const bf16_t* src = y + static_cast<size_t>(p) * d;
+  bf16_t* dst = out + static_cast<size_t>(row_index[p]) * d;
+  for (int c = lane * 8; c < d; c += 64 * 8)
+    *reinterpret_cast<bf16x8*>(dst + c) = *reinterpret_cast<const bf16x8*>(src + c);
+}
+
 }  // namespace
+
+LC_EXPORT int lc_ep_pack(const void* x, const void* sorted_src, const void* offsets, const void* slot_of, int per,
+                         int ep, int cap, int A, int d, void* send, void* send_counts, void* slot_back,
+                         hipStream_t stream) {
+  if (A <= 0 || cap <= 0) return 0;
+  if (d % 8 || ep < 1 || ep > 64 || per < 1 || ep * per > kMaxExperts) return -1;
+  const int waves = std::max(ep * cap, (std::max(A, ep * per) + 63) / 64);
+  ep_pack_kernel<<<dim3((waves + 3) / 4), dim3(256), 0, stream>>>(
+      static_cast<const bf16_t*>(x), static_cast<const int32_t*>(sorted_src), static_cast<const int32_t*>(offsets),
+      static_cast<const int32_t*>(slot_of), per, ep, cap, A, d, static_cast<bf16_t*>(send),
+      static_cast<int32_t*>(send_counts), static_cast<int32_t*>(slot_back));
+  LC_RETURN_LAST_ERROR();
+}
+
+LC_EXPORT int lc_ep_recv_index(const void* recv_counts, int ep, int per, int cap, void* row_index,
+                               void* offsets_local, hipStream_t stream) {
+  if (ep < 1 || ep > 64 || per < 1 || per > kMaxExperts || cap <= 0) return -1;
+  ep_recv_index_kernel<<<dim3(1), dim3(256), 0, stream>>>(static_cast<const int32_t*>(recv_counts), ep, per, cap,
+                                                         static_cast<int32_t*>(row_index),
+                                                         static_cast<int32_t*>(offsets_local));
+  LC_RETURN_LAST_ERROR();
+}
+
+LC_EXPORT int lc_scatter_rows(const void* y, const void* row_index, const void* total, int cap_rows, int d,
+                              void* out, hipStream_t stream) {
+  if (cap_rows <= 0) return 0;
+  if (d % 8) return -1;
+  scatter_rows_kernel<<<dim3((cap_rows + 3) / 4), dim3(256), 0, stream>>>(
+      static_cast<const bf16_t*>(y), static_cast<const int32_t*>(row_index), static_cast<const int32_t*>(total),
+      cap_rows, d, static_cast<bf16_t*>(out));
+  LC_RETURN_LAST_ERROR();
+}
 
 LC_EXPORT int lc_moe_router(const void* x, const void* Wr, int T, int d, int E, int topk, void* topk_ids,
                             void* topk_w, void* router_logits, hipStream_t stream) {

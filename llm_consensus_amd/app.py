@@ -106,7 +106,8 @@ def build_backend(spec: ModelSpec, device: torch.device, comm=None, tp_rank: int
     """One engine for ``spec``. With tp/ep > 1, ``comm`` is the model's group and this
     process holds shard ``tp_rank`` (= comm.rank); a single process ignores tp/ep."""
     grouped = comm is not None and comm.world > 1
-    model = build_model(spec, device, tp_rank=tp_rank, tp_size=spec.tp if grouped else 1, comm=comm,
+    tp_size = spec.tp if grouped else 1
+    model = build_model(spec, device, tp_rank=tp_rank if tp_size > 1 else 0, tp_size=tp_size, comm=comm,
                         ep_size=spec.ep if grouped else 1, ep_mode=spec.ep_mode)
     max_len = min(model.cfg.max_position, spec.max_model_len) if spec.max_model_len > 0 else model.cfg.max_position
     eng = Engine(model, block_size=spec.kv_block_size if device.type == "cuda" else 16,
@@ -114,7 +115,7 @@ def build_backend(spec: ModelSpec, device: torch.device, comm=None, tp_rank: int
                  max_model_len=max_len, kv_fraction=spec.kv_fraction,
                  graph_buckets=spec.graph_batch_buckets, name=spec.name, mix_decode=spec.mix_decode,
                  optimistic_admission=spec.admission == "optimistic",
-                 num_kv_blocks=None if device.type == "cuda" else 512)
+                 num_kv_blocks=spec.kv_blocks or (None if device.type == "cuda" else 512))
     tok = make_tokenizer(spec.tokenizer, model.cfg.vocab_size)
     return EngineBackend(eng, tok, name=spec.name, stop_at_eos=spec.tokenizer is not None,
                          chat_format=spec.chat_format)
@@ -165,5 +166,5 @@ def make_strategy(cfg: ConsensusConfig, members: List[Member], device):
     if cfg.strategy == "judge_logprob":
         return JudgeLogprob(voters, judges or voters[-1:], device=dev)
     if cfg.strategy == "embedding_medoid":
-        return EmbeddingMedoid(voters, (embedders or voters)[0], device=dev)
+        return EmbeddingMedoid(voters, (embedders or voters)[0], samples_per_member=cfg.samples_per_member, device=dev)
     raise ValueError(cfg.strategy)

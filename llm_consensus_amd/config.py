@@ -50,7 +50,8 @@ class ModelSpec:
     ep: int = 1
     ep_mode: str = "allreduce"        # allreduce | a2a (see parallel/ep.py)
     kv_block_size: int = 64
-    kv_fraction: float = 0.6          # share of free HBM given to the KV pool
+    kv_fraction: float = 0.6          # share of free HBM given to the KV pool (when kv_blocks is 0)
+    kv_blocks: int = 0                # explicit KV pool size in blocks; 0 = size it from kv_fraction
     max_batch_seqs: int = 256
     max_prefill_tokens: int = 8192
     mix_decode: bool = True           # decoding chains ride along in the steps that prefill new prompts
@@ -83,6 +84,7 @@ class ConsensusConfig:
     decision_mode: str = "text"       # text | logprob (constrained two-way / choice decision on device)
     forward_reasoning_to_refiner: bool = False
     k_chains: int = 16
+    samples_per_member: int = 1       # embedding_medoid: candidates sampled per proposer and question
     choices: str = "ABCD"
     tie_break: str = "lowest_class"
     deadline_s: Optional[float] = None

@@ -76,11 +76,22 @@ class EngineBackend(Backend):
 
     incremental = True
 
+    def _group_failure(self, e: BaseException) -> None:
+        """A failed step of a tensor / expert parallel member cannot be absorbed locally: the
+        other ranks of the group are inside (or about to enter) a collective this rank will
+        never join. The only state all ranks can agree on again is "the group is down", so
+        the error leaves the process (the launcher ends the other ranks)."""
+        m = self.engine.model
+        if m.tp_size > 1 or m.ep_size > 1:
+            raise RuntimeError(f"{self.name}: step failed on rank {m.comm.rank} of a {m.comm.world}-rank "
+                               f"model group; the group cannot continue") from e
+
     def run(self) -> None:
         try:
             self.engine.run_until_done()
         except Exception as e:  # noqa: BLE001  a failed step (HIP / RCCL error, bad shapes) fails its requests only
             self._fail_all(e)
+            self._group_failure(e)
             return
         self._harvest(final=True)
 
@@ -91,6 +102,7 @@ class EngineBackend(Backend):
                 self.engine.step()
         except Exception as e:  # noqa: BLE001
             self._fail_all(e)
+            self._group_failure(e)
             return False
         self._harvest(final=not self.engine.has_work())
         return bool(self._pending)
@@ -110,6 +122,7 @@ class EngineBackend(Backend):
         and is ready for new work. The process keeps serving."""
         log.error("%s: engine step failed, %d request(s) dropped: %s: %s", self.name, len(self._pending),
                   type(e).__name__, e)
+        log.debug("%s: traceback of the failed step", self.name, exc_info=e)
         for rid, (_, h) in self._pending.items():
             if not h.done:
                 h.set_error(BackendError(f"engine failure: {type(e).__name__}: {e}"))

@@ -563,6 +563,88 @@ def _expert_mlp_cpu(xe: torch.Tensor, w_gate_up: "ExpertWeights", w_down: "Exper
     return ref.linear(act, w_down.data[e], None, xe.dtype).float()
 
 
+def moe_permute(ids: torch.Tensor, E: int):
+    """Sorts the (token, k) pairs of ``ids`` [T, k] by expert, keeping token order inside an
+    expert. Returns (offsets int32 [E+1], sorted_src int32 [T*k]: token row of every sorted
+    position, slot_of int32 [T*k]: sorted position of pair t*k + j)."""
+    T, topk = ids.shape
+    A = T * topk
+    dev = ids.device
+    if not ids.is_cuda:
+        flat = ids.reshape(-1).long()
+        order = torch.argsort(flat, stable=True)
+        counts = torch.bincount(flat, minlength=E)
+        offsets = torch.zeros(E + 1, dtype=torch.int32)
+        offsets[1:] = torch.cumsum(counts, 0).to(torch.int32)
+        slot_of = torch.empty(A, dtype=torch.int32)
+        slot_of[order] = torch.arange(A, dtype=torch.int32)
+        return offsets, (order // topk).to(torch.int32), slot_of
+    h = _hip()
+    offsets = torch.empty(E + 1, dtype=torch.int32, device=dev)
+    sorted_src = torch.empty(A, dtype=torch.int32, device=dev)
+    slot_of = torch.empty(A, dtype=torch.int32, device=dev)
+    h.call("lc_moe_permute", ids.data_ptr(), T, topk, E, offsets.data_ptr(), sorted_src.data_ptr(), slot_of.data_ptr())
+    return offsets, sorted_src, slot_of
+
+
+def experts_on_sorted(x: torch.Tensor, row_index: Optional[torch.Tensor], offsets: torch.Tensor, expert0: int,
+                      w_gate_up: "ExpertWeights", w_down: "ExpertWeights", rows_bound: int,
+                      zero_unwritten: bool = False) -> torch.Tensor:
+    """The resident experts' SwiGLU MLPs over rows in expert-sorted order. Sorted position p
+    in [offsets[expert0 + e], offsets[expert0 + e + 1]) belongs to resident expert e and reads
+    ``x[row_index[p]]``. Returns y [rows_bound, d]; positions outside the resident experts'
+    ranges are left unwritten (zero with ``zero_unwritten``). ``rows_bound`` (a host integer)
+    bounds every offset, so nothing here waits for the device."""
+    E_local = w_gate_up.data.shape[0]
+    d = w_down.n
+    dff = w_gate_up.n // 2
+    dev = x.device
+    if not x.is_cuda:
+        y = torch.zeros(rows_bound, d, dtype=x.dtype)
+        for e in range(E_local):
+            lo, hi = int(offsets[expert0 + e]), int(offsets[expert0 + e + 1])
+            if hi > lo:
+                rows = x[row_index[lo:hi].long()] if row_index is not None else x[lo:hi]
+                y[lo:hi] = _expert_mlp_cpu(rows, w_gate_up, w_down, e).to(x.dtype)
+        return y
+    h = _hip()
+    off_ptr = offsets.data_ptr() + 4 * expert0          # the kernels index rows by absolute offsets
+    act = torch.empty(rows_bound, dff, dtype=x.dtype, device=dev)
+    y = (torch.zeros if zero_unwritten else torch.empty)(rows_bound, d, dtype=x.dtype, device=dev)
+    # Decode steps (a few dozen routed rows in total): every expert's weights are streamed once
+    # against one small panel. Prefill-sized batches use the tiled grouped kernels.
+    gg = "lc_gemm_panel_grouped" if rows_bound <= MOE_PANEL_MAX_ROWS else "lc_gemm_grouped"
+    if (gg == "lc_gemm_grouped" and rows_bound >= MOE_GEMM256_MIN_ROWS and w_gate_up.n_pad % 256 == 0
+            and w_down.n_pad % 256 == 0 and w_gate_up.k % 64 == 0 and w_down.k % 64 == 0):
+        # Prefill-sized batches: the 256x256 pipelined tile per expert. It reads contiguous rows,
+        # so the rows are first gathered into expert order (a copy of rows_bound rows, a fraction
+        # of a percent of the GEMMs' time).
+        xs = embed(row_index, x) if row_index is not None else x
+        h.call("lc_gemm256_grouped", w_gate_up.data.data_ptr(), w_gate_up.data[0].numel(), xs.data_ptr(), off_ptr,
+               E_local, act.data_ptr(), rows_bound, w_gate_up.n, w_gate_up.k, w_gate_up.n_pad, dff, EPI_SWIGLU)
+        h.call("lc_gemm256_grouped", w_down.data.data_ptr(), w_down.data[0].numel(), act.data_ptr(), off_ptr,
+               E_local, y.data_ptr(), rows_bound, w_down.n, w_down.k, w_down.n_pad, d, EPI_BF16)
+        return y
+    h.call(gg, w_gate_up.data.data_ptr(), w_gate_up.data[0].numel(), x.data_ptr(), h.ptr(row_index), off_ptr, E_local,
+           act.data_ptr(), rows_bound, w_gate_up.n, w_gate_up.k, w_gate_up.n_pad, dff, EPI_SWIGLU)
+    h.call(gg, w_down.data.data_ptr(), w_down.data[0].numel(), act.data_ptr(), None, off_ptr, E_local, y.data_ptr(),
+           rows_bound, w_down.n, w_down.k, w_down.n_pad, d, EPI_BF16)
+    return y
+
+
+def moe_combine(y: torch.Tensor, slot_of: torch.Tensor, wts: torch.Tensor, T: int) -> torch.Tensor:
+    """out[t] = sum_k wts[t, k] * y[slot_of[t*k + j]] (fp32 accumulation, activation dtype out)."""
+    topk = wts.shape[1]
+    d = y.shape[1]
+    if not y.is_cuda:
+        rows = y[slot_of.long()].float().view(T, topk, d)
+        return (rows * wts.float()[:, :, None]).sum(1).to(y.dtype)
+    h = _hip()
+    out = torch.empty(T, d, dtype=y.dtype, device=y.device)
+    h.call("lc_moe_combine", y.data_ptr(), slot_of.data_ptr(), wts.data_ptr(), out.data_ptr(), T, d, topk)
+    return out
+
+
 def moe_experts(x: torch.Tensor, ids: torch.Tensor, wts: torch.Tensor, w_gate_up: "ExpertWeights",
                 w_down: "ExpertWeights", expert_lo: int = 0, n_experts: Optional[int] = None) -> torch.Tensor:
     """sum_k wts[t,k] * MLP_{ids[t,k]}(x[t]) over the experts held in ``w_*`` (global ids
@@ -572,48 +654,74 @@ def moe_experts(x: torch.Tensor, ids: torch.Tensor, wts: torch.Tensor, w_gate_up
     topk = ids.shape[1]
     E_local = w_gate_up.data.shape[0]
     E = n_experts or (expert_lo + E_local)
-    if not x.is_cuda:
-        out = torch.zeros(T, d, dtype=torch.float32)
-        for e in range(E_local):
-            tok, slot = torch.nonzero(ids == expert_lo + e, as_tuple=True)
-            if tok.numel():
-                out.index_add_(0, tok, _expert_mlp_cpu(x[tok], w_gate_up, w_down, e) * wts[tok, slot][:, None])
-        return out.to(x.dtype)
+    offsets, sorted_src, slot_of = moe_permute(ids, E)
+    y = experts_on_sorted(x, sorted_src, offsets, expert_lo, w_gate_up, w_down, T * topk, zero_unwritten=E_local != E)
+    return moe_combine(y, slot_of, wts, T)
+
+
+# ---- expert-parallel exchange pieces (parallel/ep.py strings them together) ----
+def ep_pack(xs: torch.Tensor, sorted_src: torch.Tensor, offsets: torch.Tensor, slot_of: torch.Tensor, per: int,
+            ep: int, cap: int):
+    """Send layout of one rank: ``send`` [ep*cap, d] (rows j < count of destination r at
+    r*cap + j, in expert-sorted order), ``send_counts`` int32 [ep*per] (pairs per expert) and
+    ``slot_back`` int32 [A]: row of the returned [ep*cap, d] buffer holding pair a's output."""
+    A = slot_of.numel()
+    d = xs.shape[1]
+    dev = xs.device
+    if not xs.is_cuda:
+        send = torch.zeros(ep * cap, d, dtype=xs.dtype)
+        off = offsets.long()
+        counts = (off[1:] - off[:-1]).to(torch.int32)
+        slot_back = torch.empty(A, dtype=torch.int32)
+        for r in range(ep):
+            lo, hi = int(off[r * per]), int(off[(r + 1) * per])
+            send[r * cap: r * cap + hi - lo] = xs[sorted_src[lo:hi].long()]
+            m = (slot_of >= lo) & (slot_of < hi)
+            slot_back[m] = (r * cap + slot_of[m] - lo).to(torch.int32)
+        return send, counts, slot_back
     h = _hip()
-    dev = x.device
-    offsets = torch.empty(E + 1, dtype=torch.int32, device=dev)
-    sorted_src = torch.empty(T * topk, dtype=torch.int32, device=dev)
-    slot_of = torch.empty(T * topk, dtype=torch.int32, device=dev)
-    h.call("lc_moe_permute", ids.data_ptr(), T, topk, E, offsets.data_ptr(), sorted_src.data_ptr(), slot_of.data_ptr())
-    off_local = offsets.data_ptr() + 4 * expert_lo          # the kernels index rows by absolute offsets
-    partial = E_local != E
-    dff = w_gate_up.n // 2
-    act = torch.empty(T * topk, dff, dtype=x.dtype, device=dev)
-    # Decode steps (a few dozen routed rows in total): every expert's weights are streamed once
-    # against one small panel. Prefill-sized batches use the tiled grouped kernel.
-    gg = "lc_gemm_panel_grouped" if T * topk <= MOE_PANEL_MAX_ROWS else "lc_gemm_grouped"
-    if (gg == "lc_gemm_grouped" and T * topk >= MOE_GEMM256_MIN_ROWS and w_gate_up.n_pad % 256 == 0
-            and w_down.n_pad % 256 == 0 and w_gate_up.k % 64 == 0 and w_down.k % 64 == 0):
-        # Prefill-sized batches: the 256x256 pipelined tile per expert. It reads contiguous rows,
-        # so the tokens are first gathered into expert order (a copy of T*topk rows, a fraction
-        # of a percent of the GEMMs' time).
-        xs = embed(sorted_src, x)
-        h.call("lc_gemm256_grouped", w_gate_up.data.data_ptr(), w_gate_up.data[0].numel(), xs.data_ptr(), off_local,
-               E_local, act.data_ptr(), T * topk, w_gate_up.n, w_gate_up.k, w_gate_up.n_pad, dff, EPI_SWIGLU)
-        y = (torch.zeros if partial else torch.empty)(T * topk, d, dtype=x.dtype, device=dev)
-        h.call("lc_gemm256_grouped", w_down.data.data_ptr(), w_down.data[0].numel(), act.data_ptr(), off_local,
-               E_local, y.data_ptr(), T * topk, w_down.n, w_down.k, w_down.n_pad, d, EPI_BF16)
-        out = torch.empty(T, d, dtype=x.dtype, device=dev)
-        h.call("lc_moe_combine", y.data_ptr(), slot_of.data_ptr(), wts.data_ptr(), out.data_ptr(), T, d, topk)
+    send = torch.empty(ep * cap, d, dtype=xs.dtype, device=dev)
+    counts = torch.empty(ep * per, dtype=torch.int32, device=dev)
+    slot_back = torch.empty(A, dtype=torch.int32, device=dev)
+    h.call("lc_ep_pack", xs.data_ptr(), sorted_src.data_ptr(), offsets.data_ptr(), slot_of.data_ptr(), per, ep, cap, A,
+           d, send.data_ptr(), counts.data_ptr(), slot_back.data_ptr())
+    return send, counts, slot_back
+
+
+def ep_recv_index(recv_counts: torch.Tensor, ep: int, per: int, cap: int):
+    """From the received per-(source, expert) counts: (row_index int32 [ep*cap]: receive-buffer
+    row of every expert-sorted position, offsets_local int32 [per+1])."""
+    dev = recv_counts.device
+    if not recv_counts.is_cuda:
+        c = recv_counts.view(ep, per).long()
+        row_index = torch.zeros(ep * cap, dtype=torch.int32)
+        offsets = torch.zeros(per + 1, dtype=torch.int32)
+        pos = 0
+        for e in range(per):
+            offsets[e] = pos
+            for s in range(ep):
+                n, start = int(c[s, e]), int(c[s, :e].sum())
+                row_index[pos:pos + n] = torch.arange(s * cap + start, s * cap + start + n, dtype=torch.int32)
+                pos += n
+        offsets[per] = pos
+        return row_index, offsets
+    h = _hip()
+    row_index = torch.empty(ep * cap, dtype=torch.int32, device=dev)
+    offsets = torch.empty(per + 1, dtype=torch.int32, device=dev)
+    h.call("lc_ep_recv_index", recv_counts.data_ptr(), ep, per, cap, row_index.data_ptr(), offsets.data_ptr())
+    return row_index, offsets
+
+
+def scatter_rows(y: torch.Tensor, row_index: torch.Tensor, total: torch.Tensor) -> torch.Tensor:
+    """out[row_index[p]] = y[p] for p < total[0] (a device integer); other rows are unspecified."""
+    if not y.is_cuda:
+        out = torch.zeros_like(y)
+        n = int(total[0])
+        out[row_index[:n].long()] = y[:n]
         return out
-    h.call(gg, w_gate_up.data.data_ptr(), w_gate_up.data[0].numel(), x.data_ptr(),
-           sorted_src.data_ptr(), off_local, E_local, act.data_ptr(), T * topk, w_gate_up.n, w_gate_up.k,
-           w_gate_up.n_pad, dff, EPI_SWIGLU)
-    y = (torch.zeros if partial else torch.empty)(T * topk, d, dtype=x.dtype, device=dev)
-    h.call(gg, w_down.data.data_ptr(), w_down.data[0].numel(), act.data_ptr(), None,
-           off_local, E_local, y.data_ptr(), T * topk, w_down.n, w_down.k, w_down.n_pad, d, EPI_BF16)
-    out = torch.empty(T, d, dtype=x.dtype, device=dev)
-    h.call("lc_moe_combine", y.data_ptr(), slot_of.data_ptr(), wts.data_ptr(), out.data_ptr(), T, d, topk)
+    h = _hip()
+    out = torch.empty_like(y)
+    h.call("lc_scatter_rows", y.data_ptr(), row_index.data_ptr(), total.data_ptr(), y.shape[0], y.shape[1], out.data_ptr())
     return out
 
 

@@ -49,6 +49,9 @@ _SIGNATURES = {
     "lc_moe_router": [_P, _P, _I, _I, _I, _I, _P, _P, _P, _P],
     "lc_moe_permute": [_P, _I, _I, _I, _P, _P, _P, _P],
     "lc_moe_combine": [_P, _P, _P, _P, _I, _I, _I, _P],
+    "lc_ep_pack": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P],
+    "lc_ep_recv_index": [_P, _I, _I, _I, _P, _P, _P],
+    "lc_scatter_rows": [_P, _P, _P, _I, _I, _P, _P],
 }
 
 _lib = None

@@ -11,7 +11,8 @@ model:
     all_gather_cols   vocab-parallel logits -> full logits
     all_gather_rows   candidate answers / votes / log-probs / embeddings to every rank
     broadcast         winning answer / next-round prompt
-    all_to_all_rows   expert-parallel token dispatch and combine
+    all_to_all_equal  expert-parallel token dispatch and combine (fixed-capacity blocks)
+    all_to_all_rows   ragged all-to-all (host-known split sizes)
 
 ``TorchDistComm`` runs them through ``torch.distributed`` (backend "nccl" is RCCL over
 xGMI on ROCm; "gloo" on CPU for tests). ``LoopbackComm`` implements the same calls over
@@ -42,6 +43,11 @@ class Comm:
         return t
 
     def all_to_all_rows(self, t: torch.Tensor, send_counts: Sequence[int], recv_counts: Sequence[int]) -> torch.Tensor:
+        return t
+
+    def all_to_all_equal(self, t: torch.Tensor) -> torch.Tensor:
+        """All-to-all with equal splits: ``t`` is ``world`` blocks of equal length along dim 0,
+        block r goes to rank r; the result's block s is what rank s sent here."""
         return t
 
     def barrier(self) -> None:
@@ -105,6 +111,12 @@ class TorchDistComm(Comm):
         out = torch.empty((int(sum(recv_counts)),) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
         self.dist.all_to_all_single(out, t.contiguous(), list(map(int, recv_counts)), list(map(int, send_counts)),
                                     group=self.group)
+        return out
+
+    def all_to_all_equal(self, t: torch.Tensor) -> torch.Tensor:
+        t = t.contiguous()
+        out = torch.empty_like(t)
+        self.dist.all_to_all_single(out, t, group=self.group)
         return out
 
     def barrier(self) -> None:
@@ -203,6 +215,11 @@ class LoopbackComm(Comm):
             off = sum(counts[src][: self.rank])
             out.append(parts[src][off: off + counts[src][self.rank]])
         return torch.cat(out, dim=0)
+
+    def all_to_all_equal(self, t: torch.Tensor) -> torch.Tensor:
+        parts = self._exchange(t.contiguous())
+        n = t.shape[0] // self.world
+        return torch.cat([p[self.rank * n:(self.rank + 1) * n] for p in parts], dim=0)
 
     def barrier(self) -> None:
         self.hub.barrier.wait()

@@ -16,15 +16,21 @@ schemes produce the replicated FFN output:
 ``a2a``        each rank takes a 1/ep slice of the tokens, routes it, sends every
                (token, k) row to the expert's owner with all-to-all, receives the MLP
                outputs back the same way, combines, and the slices are all-gathered.
-               Traffic 2*(T/ep)*k*d*(ep-1)/ep + T*d per rank: less than the all-reduce
-               when k < ep, and no rank multiplies rows for experts it does not own.
-               Split sizes are data dependent (one small D2H per layer).
+               Every (source, destination) pair owns a fixed number of rows (``cap``) of
+               the exchange buffers, so all three exchanges have equal splits and the
+               per-expert row counts travel as data: up to EP_FIXED_MAX_ROWS routed rows
+               per rank (decode steps) cap is the worst case and nothing waits for the
+               host; above that (prefill chunks) the ranks agree on the largest actual
+               count first, which costs one device->host read per layer and keeps the
+               buffers close to the T/ep*k*d bytes a rank really has to send. No rank
+               multiplies rows for experts it does not own.
 
 On xGMI all-to-all maps to direct peer writes over the point-to-point links (every pair of
 GPUs in a node has its own link), which is the collective this fabric is best at.
 """
 from __future__ import annotations
 
+import os
 from typing import Tuple
 
 import torch
@@ -46,47 +52,41 @@ def moe_allreduce(x, Wr, w_gate_up, w_down, topk: int, comm: Comm, expert_lo: in
     return out
 
 
+# Routed rows per rank (tokens/ep * top-k) up to which the exchange buffers are sized for the
+# worst case (every pair of a rank bound for one destination) instead of the measured maximum.
+EP_FIXED_MAX_ROWS = int(os.environ.get("LC_EP_FIXED_ROWS", "256"))
+
+
 def moe_all_to_all(x, Wr, w_gate_up, w_down, topk: int, comm: Comm, expert_lo: int) -> torch.Tensor:
     T, d = x.shape
     ep, r = comm.world, comm.rank
     E = Wr.shape[0]
     per = E // ep
-    # ---- this rank's token slice (padded so all slices have equal length for the gather)
+    # ---- this rank's token slice, padded with zero rows to the common slice length
     tl = (T + ep - 1) // ep
     lo, hi = min(T, r * tl), min(T, (r + 1) * tl)
     xs = x[lo:hi]
-    n = hi - lo
-    ids, wts = ops.moe_route(xs, Wr, topk) if n else (
-        torch.empty(0, topk, dtype=torch.int32, device=x.device), torch.empty(0, topk, device=x.device))
-    # ---- sort (token, k) pairs by destination rank
-    flat_e = ids.reshape(-1).long()
-    dest = flat_e // per
-    order = torch.argsort(dest, stable=True)
-    send_counts = torch.bincount(dest, minlength=ep)
-    counts = comm.all_gather_rows(send_counts.to(torch.int64).view(1, ep))      # [ep, ep]: row s = sends of rank s
-    counts_host = counts.cpu()
-    sc = counts_host[r].tolist()
-    rc = counts_host[:, r].tolist()
-    tok_of = torch.div(order, topk, rounding_mode="floor")
-    send_rows = xs[tok_of]
-    send_eid = (flat_e[order] - dest[order] * per).to(torch.int32).view(-1, 1)
-    recv_rows = comm.all_to_all_rows(send_rows, sc, rc)
-    recv_eid = comm.all_to_all_rows(send_eid, sc, rc)
-    # ---- resident experts on the received rows (top-1 "routing" with unit weights)
-    R = recv_rows.shape[0]
-    if R:
-        ones = torch.ones(R, 1, dtype=torch.float32, device=x.device)
-        y = ops.moe_experts(recv_rows.contiguous(), recv_eid.contiguous(), ones, w_gate_up, w_down, 0, per)
+    if hi - lo < tl:
+        xs = torch.cat([xs, x.new_zeros(tl - (hi - lo), d)], 0)
+    xs = xs.contiguous()
+    ids, wts = ops.moe_route(xs, Wr, topk)
+    offsets, sorted_src, slot_of = ops.moe_permute(ids, E)       # expert order == destination order
+    A = tl * topk
+    if A <= EP_FIXED_MAX_ROWS:
+        cap = A
     else:
-        y = recv_rows
-    # ---- return to the senders, combine per token
-    back = comm.all_to_all_rows(y, rc, sc)
-    out = torch.zeros(tl, d, dtype=torch.float32, device=x.device)
-    if n:
-        w_sorted = wts.reshape(-1)[order]
-        out.index_add_(0, tok_of, back.float() * w_sorted[:, None])
-    full = comm.all_gather_rows(out.to(x.dtype))
-    return full[:T].contiguous()
+        off = offsets[::per].to(torch.int64)                      # [ep + 1] destination boundaries
+        most = comm.all_gather_rows((off[1:] - off[:-1]).max().view(1, 1))
+        cap = max(64, -(-int(most.max().item()) // 64) * 64)      # the one host read of this layer
+    send, send_counts, slot_back = ops.ep_pack(xs, sorted_src, offsets, slot_of, per, ep, cap)
+    recv = comm.all_to_all_equal(send)                            # [ep*cap, d]: block s came from rank s
+    recv_counts = comm.all_to_all_equal(send_counts)              # [ep*per]
+    row_index, off_local = ops.ep_recv_index(recv_counts, ep, per, cap)
+    y = ops.experts_on_sorted(recv, row_index, off_local, 0, w_gate_up, w_down, ep * cap)
+    back = comm.all_to_all_equal(ops.scatter_rows(y, row_index, off_local[per:]))
+    out = ops.moe_combine(back, slot_back, wts, tl)
+    full = comm.all_gather_rows(out)
+    return full[:T] if ep * tl != T else full
 
 
 def moe_ffn_ep(x, Wr, w_gate_up, w_down, topk: int, comm: Comm, expert_lo: int, mode: str = "allreduce"):

@@ -1,0 +1,79 @@
+"""bench.py's own plumbing on CPU: the launcher really starts one rank per requested device
+(gloo, tiny presets), the JSON line reports what ran, and mismatches are errors. The
+reference's defining behaviour is concurrent fan-out to all members
+(/root/reference/src/main.rs:250-253); a benchmark that silently ran on one device would
+measure none of it."""
+import json
+import os
+import subprocess
+import sys
+from pathlib import Path
+
+import pytest
+
+ROOT = Path(__file__).resolve().parents[1]
+TINY = ["--device", "cpu", "--models", "tiny-llama,tiny-qwen,tiny-mistral", "--questions", "2", "--prompt-len", "64",
+        "--new-tokens", "4", "--steps", "1", "--warmup", "0", "--sc-questions", "1", "--k-chains", "4",
+        "--proto-questions", "1", "--proto-prompt-len", "64", "--judge-questions", "2", "--judge-model", "tiny-qwen",
+        "--proposer-model", "tiny-llama", "--moe-questions", "2", "--moe-model", "tiny-mixtral", "--moe-experts", "4",
+        "--embed-model", "tiny-llama", "--moe-samples", "2", "--skip-stream"]
+
+
+def run_bench(args, env=None, timeout=300):
+    e = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    e.update(env or {})
+    return subprocess.run([sys.executable, str(ROOT / "bench.py")] + args, capture_output=True, text=True, env=e,
+                          timeout=timeout)
+
+
+def json_line(p):
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, (p.stdout[-2000:], p.stderr[-2000:])
+    return json.loads(lines[0])
+
+
+def test_gpus_flag_launches_that_many_ranks_for_every_workload():
+    p = run_bench(["--gpus", "2", "--workload", "A,D,E"] + TINY)
+    assert p.returncode == 0, p.stderr[-3000:]
+    out = json_line(p)
+    assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 4 and out["value"] > 0
+    assert out["steps"] == 1 and out["warmup"] == 0 and out["higher_is_better"] is True
+    d, e = out["judge_consensus"], out["moe_medoid"]
+    assert d["judge_tp"] == 2 and d["placement"]["gpus_per_replica"] == 2 and d["value"] > 0
+    assert e["expert_parallel"] == 2 and e["ep_mode"] == "a2a" and e["value"] > 0
+    assert d["mean_member_calls"] == 4 + 4 * 1           # four proposals + four judge scores per question
+
+
+def test_single_rank_line_has_every_section_and_the_contract_fields():
+    p = run_bench(["--workload", "all"] + TINY)
+    assert p.returncode == 0, p.stderr[-3000:]
+    out = json_line(p)
+    assert out["n_gpus"] == 1 and out["config"]["global_batch"] == 2
+    for key in ("metric", "value", "unit", "ms_per_step", "scaling", "vs_baseline", "dtype", "data", "config"):
+        assert out[key] is not None, key
+    for sec in ("self_consistency", "reference_protocol", "reference_protocol_persona_last", "judge_consensus",
+                "moe_medoid"):
+        assert out[sec]["value"] > 0 and out[sec]["p50_latency_ms"] > 0, sec
+    assert out["judge_consensus"]["judge_tp"] == 1 and out["moe_medoid"]["expert_parallel"] == 1
+
+
+def test_spread_placement_puts_one_model_per_rank():
+    p = run_bench(["--gpus", "3", "--workload", "A", "--placement", "spread"] + TINY)
+    assert p.returncode == 0, p.stderr[-3000:]
+    out = json_line(p)
+    assert out["n_gpus"] == 3 and out["config"]["placement"]["gpus_per_replica"] == 3
+    assert out["config"]["global_batch"] == 2
+    gpus = out["config"]["placement"]["replica0_member_gpus"]
+    assert sorted(g[0] for g in gpus.values()) == [0, 1, 2]
+
+
+def test_mismatches_are_errors_not_silent_single_device_runs():
+    p = run_bench(["--gpus", "4", "--workload", "A"] + TINY, env={"WORLD_SIZE": "2", "RANK": "0"})
+    assert p.returncode == 2 and "disagrees" in p.stderr and not p.stdout.strip()
+    import torch
+
+    if torch.cuda.device_count() < 3:
+        q = run_bench(["--gpus", "3", "--workload", "A"])
+        assert q.returncode == 2 and "visible" in q.stderr and not q.stdout.strip()
+    r = run_bench(["--gpus", "2", "--workload", "A", "--placement", "spread"] + TINY)
+    assert r.returncode != 0 and "spread" in r.stderr

@@ -87,6 +87,30 @@ def test_expert_parallel_four_ranks_uneven_token_count():
         assert np.allclose(got, want, atol=0.05)
 
 
+def test_expert_parallel_a2a_measured_capacity_path(monkeypatch):
+    """Above EP_FIXED_MAX_ROWS routed rows per rank the exchange buffers are sized from the
+    largest actual per-destination count (agreed on by all ranks) instead of the worst case;
+    the result must not change. The exchange itself is built from the permute / pack / index
+    kernels' outputs: no sort, histogram or host copy in parallel/ep.py."""
+    import inspect
+
+    from llm_consensus_amd.parallel import ep
+
+    src = inspect.getsource(ep.moe_all_to_all)
+    for banned in ("argsort", "bincount", "index_add_", ".cpu()"):
+        assert banned not in src, banned
+    cfg = get_preset("tiny-mixtral")
+    want, _ = _probe(TransformerModel.random_init(cfg, "cpu", seed=12, std=0.08), PROMPTS, TARGETS)
+    monkeypatch.setattr(ep, "EP_FIXED_MAX_ROWS", 2)
+
+    def rank(comm):
+        m = TransformerModel.random_init(cfg, "cpu", seed=12, std=0.08, comm=comm, ep_size=2, ep_mode="a2a")
+        return _probe(m, PROMPTS, TARGETS)
+
+    for got, _ in run_loopback(2, rank):
+        assert np.allclose(got, want, atol=0.05), np.abs(got - want).max()
+
+
 def test_invalid_parallel_layouts_are_rejected():
     with pytest.raises(ValueError):
         TransformerModel(get_preset("tiny-llama"), "cpu", tp_size=4)          # 2 KV heads
