@@ -377,16 +377,21 @@ class Engine:
                             if c < 2 * self.max_model_len] or [256]
         self.max_decision = max_decision
         self.max_group_rows = max_group_rows
-        # Decode steps are captured into hipGraphs by default. Steps that contain collectives
-        # (tensor / expert parallel members) run eagerly unless asked otherwise: capturing RCCL
-        # calls needs every rank of the group to capture and replay in lock step, and with
-        # torch 2.10 + ROCm 7.2 a stream capture that contained a torch.distributed all-reduce
-        # ended the process (even at world size 1), so CONSENSUS_GRAPH_COLLECTIVES=1 is an
-        # experiment switch, not a supported mode.
+        # Decode steps are captured into hipGraphs by default. A step that contains collectives
+        # (tensor / expert parallel members) is captured like any other when the group's
+        # communicator is made of plain kernel launches (``capturable``: parallel/p2p.py).
+        # torch.distributed collectives are not captured: see the note in parallel/comm.py
+        # (TorchDistComm); such members run eagerly or from the cut modes below, and asking for
+        # graphs explicitly is an error rather than a way to end the process.
         sharded = model.tp_size > 1 or model.ep_size > 1
+        capturable = not sharded or bool(getattr(model.comm, "capturable", False))
         use_graphs_arg = use_graphs
         if use_graphs is None:
-            use_graphs = not sharded or os.environ.get("CONSENSUS_GRAPH_COLLECTIVES", "0") == "1"
+            use_graphs = capturable
+        elif use_graphs and not capturable and self.device.type == "cuda" and \
+                os.environ.get("CONSENSUS_GRAPH_COLLECTIVES", "0") != "1":
+            raise ValueError(f"{name}: use_graphs=True needs a capturable group communicator (parallel.p2p.P2PComm); "
+                             f"{type(model.comm).__name__} issues library collectives that cannot be captured")
         self.use_graphs = bool(use_graphs) and self.device.type == "cuda"
         # Tensor-parallel members: graphs cut at the collectives (see capture_piecewise). Expert
         # parallel steps have data-dependent exchange sizes and stay eager.

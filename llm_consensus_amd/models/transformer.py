@@ -204,10 +204,21 @@ class TransformerModel:
         return n
 
     # ------------------------------------------------------------------ forward
-    def _all_reduce(self, t: torch.Tensor) -> torch.Tensor:
-        if self.tp_size > 1:
-            self.comm.all_reduce(t)
-        return t
+    def _reduce_norm(self, h: torch.Tensor, delta, w: torch.Tensor) -> torch.Tensor:
+        """RMSNorm(h += delta) * w, h updated in place. Under tensor parallelism ``delta`` is this
+        rank's PARTIAL product (row-parallel O / down projection): it is summed over the group
+        first. A communicator with ``allreduce_rmsnorm`` (parallel/p2p.py) does sum, residual
+        add and norm in one launch, split-K slabs included; otherwise all-reduce, then the
+        fused residual-norm kernel."""
+        eps = self.cfg.rms_eps
+        if self.tp_size > 1 and delta is not None:
+            fused = getattr(self.comm, "allreduce_rmsnorm", None)
+            if fused is not None and h.is_cuda:
+                return fused(h, delta, w, eps)
+            if isinstance(delta, ops.PartialSum):
+                delta = delta.reduce()
+            delta = self.comm.all_reduce(delta)
+        return ops.rmsnorm(h, w, eps, delta)
 
     def forward(self, token_ids: torch.Tensor, positions: torch.Tensor, slot_mapping: torch.Tensor,
                 meta: AttnMeta, kv: KVCache) -> torch.Tensor:
@@ -215,9 +226,8 @@ class TransformerModel:
         c = self.cfg
         h = ops.embed(token_ids, self.embed)
         delta = None
-        defer = self.tp_size == 1   # an all-reduce needs the reduced tensor; the fused norm does not
         for i, L in enumerate(self.layers):
-            x = ops.rmsnorm(h, L.ln1, c.rms_eps, delta)
+            x = self._reduce_norm(h, delta, L.ln1)
             qkv = ops.linear(x, L.qkv, defer_reduce=True)
             kc, vc = kv.k(i), kv.vt(i)
             qkv = ops.rope_kv_write(qkv, positions, slot_mapping, self.cos_t, self.sin_t, kc, vc, self.hq, self.hkv,
@@ -238,17 +248,15 @@ class TransformerModel:
                 a = ops.attn_decode(qkv, kc, vc, meta.block_tables, meta.ctx_lens, self.hq, self.hkv, c.head_dim,
                                     self.scale, c.sliding_window, meta.nsplit, meta.groups, meta.kv_begin,
                                     meta.max_group_rows, meta.prefix_splits)
-            o = self._all_reduce(ops.linear(a, L.o, defer_reduce=defer))
-            x2 = ops.rmsnorm(h, L.ln2, c.rms_eps, o)
+            x2 = self._reduce_norm(h, ops.linear(a, L.o, defer_reduce=True), L.ln2)
             if c.is_moe and self.ep_size > 1:
                 delta = moe_ffn_ep(x2, L.router, L.experts_gate_up, L.experts_down, c.experts_per_tok, self.comm,
                                    self.expert_lo, self.ep_mode)
             elif c.is_moe:
-                delta = self._all_reduce(ops.moe_ffn(x2, L.router, L.experts_gate_up, L.experts_down,
-                                                     c.experts_per_tok))
+                delta = ops.moe_ffn(x2, L.router, L.experts_gate_up, L.experts_down, c.experts_per_tok)
             else:
-                delta = self._all_reduce(ops.linear(ops.linear(x2, L.gate_up), L.down, defer_reduce=defer))
-        return ops.rmsnorm(h, self.final_norm, c.rms_eps, delta)
+                delta = ops.linear(ops.linear(x2, L.gate_up), L.down, defer_reduce=True)
+        return self._reduce_norm(h, delta, self.final_norm)
 
     def logits(self, hidden_rows: torch.Tensor) -> torch.Tensor:
         """fp32 logits [R, V] for the given hidden rows (vocab-parallel + all-gather under TP)."""

@@ -1,0 +1,276 @@
+"""Peer-to-peer collectives of one model group (csrc/kernels/p2p.hip) behind the ``Comm`` interface.
+
+Every rank of a tensor- or expert-parallel group allocates one exchange region, hands its
+HIP IPC handle to the other ranks (one host-side all-gather at start-up, through whatever
+communicator bootstraps the group: RCCL or gloo process groups, or the in-process loopback
+hub), and maps theirs. From then on the group's hot collectives are single kernel launches
+that read and write the peers' regions over xGMI:
+
+    allreduce_rmsnorm  sum of the ranks' partial products + residual add + RMSNorm (the two
+                       per-layer reductions of a tensor-parallel transformer block)
+    all_reduce         plain sum of bf16 [T, d] tensors
+    all_gather_cols / all_gather_rows / all_to_all_equal   byte exchanges
+
+They contain no RCCL call and no host synchronisation, so a decode step that uses them is
+captured into one hipGraph like an unsharded one (``capturable``). Everything else
+(broadcasts of Python objects, barriers, ragged all-to-all) goes to the bootstrap
+communicator.
+
+The reference's members never talk to each other directly; all of its traffic is
+coordinator <-> member messages on one thread (/root/reference/src/main.rs:234, 250-253).
+This module exists because one *member* here can span several GPUs.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import c_double, c_float, c_int, c_longlong, c_void_p
+from typing import List, Optional
+
+import torch
+
+from .comm import Comm
+
+_lib = None
+
+
+def _L():
+    global _lib
+    if _lib is None:
+        from .._native import kernels
+
+        l = kernels()
+        l.lc_p2p_region_bytes.argtypes, l.lc_p2p_region_bytes.restype = [c_longlong], c_longlong
+        l.lc_p2p_alloc.argtypes, l.lc_p2p_alloc.restype = [c_longlong, ctypes.POINTER(c_void_p), c_void_p], c_int
+        l.lc_p2p_open.argtypes, l.lc_p2p_open.restype = [c_void_p, ctypes.POINTER(c_void_p)], c_int
+        l.lc_p2p_close.argtypes, l.lc_p2p_close.restype = [c_void_p], c_int
+        l.lc_p2p_free.argtypes, l.lc_p2p_free.restype = [c_void_p], c_int
+        l.lc_p2p_handle_bytes.argtypes, l.lc_p2p_handle_bytes.restype = [], c_int
+        l.lc_p2p_comm_create.argtypes = [c_int, c_int, ctypes.POINTER(c_void_p), c_longlong, c_double]
+        l.lc_p2p_comm_create.restype = c_void_p
+        l.lc_p2p_comm_destroy.argtypes, l.lc_p2p_comm_destroy.restype = [c_void_p], None
+        l.lc_p2p_comm_error.argtypes, l.lc_p2p_comm_error.restype = [c_void_p], c_int
+        l.lc_p2p_comm_capacity.argtypes, l.lc_p2p_comm_capacity.restype = [c_void_p], c_longlong
+        l.lc_p2p_allreduce.argtypes = [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
+                                       c_float, c_int, c_void_p]
+        l.lc_p2p_allreduce.restype = c_int
+        l.lc_p2p_exchange.argtypes = [c_void_p, c_void_p, c_void_p, c_longlong, c_int, c_void_p]
+        l.lc_p2p_exchange.restype = c_int
+        _lib = l
+    return _lib
+
+
+# Messages (bytes per rank) above which the all-reduce runs as reduce-scatter + all-gather.
+TWO_SHOT_BYTES = int(os.environ.get("LC_P2P_TWO_SHOT_BYTES", str(1 << 20)))
+DEFAULT_STAGE_BYTES = int(os.environ.get("LC_P2P_STAGE_BYTES", str(64 << 20)))
+TIMEOUT_S = float(os.environ.get("LC_P2P_TIMEOUT_S", "20"))
+
+
+class P2PError(RuntimeError):
+    pass
+
+
+def supported(world: int, device) -> bool:
+    return world in (2, 4, 8) and torch.device(device).type == "cuda"
+
+
+class P2PComm(Comm):
+    """``base`` bootstraps the group (its ``all_gather_object`` carries the IPC handles) and
+    serves the collectives this class does not implement. All ranks of the group must
+    construct it at the same point (collective)."""
+
+    capturable = True
+
+    def __init__(self, base: Comm, device, stage_bytes: int = DEFAULT_STAGE_BYTES, timeout_s: float = TIMEOUT_S) -> None:
+        if not supported(base.world, device):
+            raise ValueError(f"P2PComm needs a CUDA device and 2, 4 or 8 ranks (got {base.world} on {device})")
+        self.base, self.rank, self.world = base, base.rank, base.world
+        self.device = torch.device(device)
+        l = _L()
+        with torch.cuda.device(self.device):
+            nbytes = l.lc_p2p_region_bytes(stage_bytes)
+            ptr = c_void_p()
+            handle = ctypes.create_string_buffer(l.lc_p2p_handle_bytes())
+            rc = l.lc_p2p_alloc(nbytes, ctypes.byref(ptr), handle)
+            if rc != 0:
+                raise P2PError(f"exchange region allocation of {nbytes} bytes failed: HIP error {rc}")
+            self._own = ptr.value
+            # (process id, device index) tells ranks that are threads of one process on one
+            # device apart from real peers: they share an address space and use the pointer.
+            me = (os.getpid(), self.device.index or 0, self._own, bytes(handle.raw))
+            peers = base.all_gather_object(me)
+            self._opened: List[int] = []
+            bases = (c_void_p * self.world)()
+            for r, (pid, dev, p, hbytes) in enumerate(peers):
+                if r == self.rank:
+                    bases[r] = self._own
+                elif pid == os.getpid():
+                    bases[r] = p
+                else:
+                    q = c_void_p()
+                    rc = l.lc_p2p_open(hbytes, ctypes.byref(q))
+                    if rc != 0:
+                        raise P2PError(f"rank {self.rank}: cannot map the exchange region of rank {r}: HIP error {rc} "
+                                       "(HSA_ENABLE_IPC_MODE_LEGACY=0 must be set in every rank's environment)")
+                    self._opened.append(q.value)
+                    bases[r] = q.value
+            self._h = l.lc_p2p_comm_create(self.world, self.rank, bases, stage_bytes, timeout_s)
+            if not self._h:
+                raise P2PError("lc_p2p_comm_create failed")
+            self.capacity = int(l.lc_p2p_comm_capacity(self._h))
+        base.barrier()      # nobody launches before every rank has mapped every region
+        self.calls = 0
+
+    # ------------------------------------------------------------------ fused all-reduce
+    def _stream(self) -> int:
+        return torch.cuda.current_stream(self.device).cuda_stream
+
+    def _check(self, rc: int, what: str) -> None:
+        if rc != 0:
+            raise P2PError(f"{what} failed: {'invalid arguments' if rc < 0 else f'HIP error {rc}'}")
+
+    def _allreduce(self, part, xin, h, w, y, T: int, d: int, eps: float) -> None:
+        l = _L()
+        rows_cap = max(1, self.capacity // (d * 2))
+        S = part.shape[0] if part is not None else 0
+        for r0 in range(0, T, rows_cap):           # same split on every rank: capacity and shapes are equal
+            n = min(rows_cap, T - r0)
+            two = 1 if n * d * 2 > TWO_SHOT_BYTES else 0
+            if part is not None and rows_cap < T:
+                # slabs of a row range are not contiguous across S: sum this range first
+                xr, pr = part[:, r0:r0 + n].sum(0).to(torch.bfloat16).contiguous(), None
+            else:
+                xr, pr = (xin[r0:r0 + n] if xin is not None else None), part
+            rc = l.lc_p2p_allreduce(
+                self._h, pr.data_ptr() if pr is not None else None, S if pr is not None else 0,
+                xr.data_ptr() if xr is not None else None, h[r0:r0 + n].data_ptr() if h is not None else None,
+                w.data_ptr() if w is not None else None, y[r0:r0 + n].data_ptr(), n, d, float(eps), two, self._stream())
+            self._check(rc, "lc_p2p_allreduce")
+            self.calls += 1
+
+    def allreduce_rmsnorm(self, h: torch.Tensor, delta, w: torch.Tensor, eps: float) -> torch.Tensor:
+        """h += sum over ranks of ``delta`` (a bf16 [T, d] tensor or an ``ops.PartialSum`` of fp32
+        split-K slabs); returns RMSNorm(h) * w. One launch."""
+        from ..ops import PartialSum
+
+        T, d = h.shape
+        y = torch.empty_like(h)
+        if isinstance(delta, PartialSum):
+            if delta.bias is not None:
+                delta = delta.reduce()
+            else:
+                self._allreduce(delta.part, None, h, w, y, T, d, eps)
+                return y
+        self._allreduce(None, delta.contiguous(), h, w, y, T, d, eps)
+        return y
+
+    def all_reduce(self, t: torch.Tensor) -> torch.Tensor:
+        if not (t.is_cuda and t.dtype == torch.bfloat16 and t.dim() == 2 and t.is_contiguous() and t.shape[1] % 8 == 0):
+            return self.base.all_reduce(t)
+        y = torch.empty_like(t)
+        self._allreduce(None, t, None, None, y, t.shape[0], t.shape[1], 0.0)
+        t.copy_(y)
+        return t
+
+    # ------------------------------------------------------------------ byte exchanges
+    def _exchange(self, src: torch.Tensor, all_to_all: bool) -> Optional[torch.Tensor]:
+        """Returns [world, ...block shape], or None when the message is not a device tensor or
+        does not fit the staging slot. Blocks that are not a multiple of 16 bytes are padded
+        (a copy on the device; the exchange stays one launch and stays capturable)."""
+        src = src.contiguous()
+        nbytes = src.numel() * src.element_size()
+        nblk = self.world if all_to_all else 1
+        m = nbytes // nblk
+        if not src.is_cuda or m == 0 or nbytes % nblk:
+            return None
+        m_pad = (m + 15) // 16 * 16
+        if m_pad * nblk > self.capacity:
+            return None
+        block_shape = ((src.shape[0] // self.world,) + tuple(src.shape[1:])) if all_to_all else tuple(src.shape)
+        raw = src.view(torch.uint8).view(nblk, m)
+        if m_pad != m:
+            padded = torch.zeros(nblk, m_pad, dtype=torch.uint8, device=src.device)
+            padded[:, :m] = raw
+            raw = padded
+        out = torch.empty(self.world, m_pad, dtype=torch.uint8, device=src.device)
+        rc = _L().lc_p2p_exchange(self._h, raw.data_ptr(), out.data_ptr(), m_pad, 1 if all_to_all else 0, self._stream())
+        self._check(rc, "lc_p2p_exchange")
+        self.calls += 1
+        if m_pad != m:
+            out = out[:, :m].contiguous()
+        return out.view(src.dtype).view((self.world,) + block_shape)
+
+    def all_gather_rows(self, t: torch.Tensor) -> torch.Tensor:
+        out = self._exchange(t, False)
+        if out is None:
+            return self.base.all_gather_rows(t)
+        return out.view((self.world * t.shape[0],) + tuple(t.shape[1:]))
+
+    def all_gather_cols(self, t: torch.Tensor, total_cols: Optional[int] = None) -> torch.Tensor:
+        out = self._exchange(t, False)
+        if out is None:
+            return self.base.all_gather_cols(t, total_cols)
+        # [W, ..., c] -> [..., W*c]
+        nd = out.dim()
+        res = out.permute(*range(1, nd - 1), 0, nd - 1).reshape(tuple(t.shape[:-1]) + (self.world * t.shape[-1],))
+        return res[..., :total_cols] if total_cols is not None else res
+
+    def all_to_all_equal(self, t: torch.Tensor) -> torch.Tensor:
+        out = self._exchange(t, True) if t.shape[0] % self.world == 0 else None
+        if out is None:
+            return self.base.all_to_all_equal(t)
+        return out.view(t.shape)
+
+    # ------------------------------------------------------------------ everything else
+    def broadcast(self, t, src=0):
+        return self.base.broadcast(t, src)
+
+    def all_to_all_rows(self, t, send_counts, recv_counts):
+        return self.base.all_to_all_rows(t, send_counts, recv_counts)
+
+    def barrier(self) -> None:
+        self.base.barrier()
+
+    def max_float(self, x):
+        return self.base.max_float(x)
+
+    def gather_floats(self, xs):
+        return self.base.gather_floats(xs)
+
+    def all_true(self, flag):
+        return self.base.all_true(flag)
+
+    def broadcast_object(self, obj, src=0):
+        return self.base.broadcast_object(obj, src)
+
+    def all_gather_object(self, obj):
+        return self.base.all_gather_object(obj)
+
+    def subgroup(self, ranks):
+        return self.base.subgroup(ranks)
+
+    def check(self) -> None:
+        """Raises if a kernel of this communicator gave up waiting for a peer (synchronises)."""
+        e = _L().lc_p2p_comm_error(self._h)
+        if e != 0:
+            raise P2PError(f"rank {self.rank}: peer-to-peer collective timed out waiting for rank {e - 1}"
+                           if e > 0 else "cannot read the communicator's error word")
+
+    def close(self) -> None:
+        l = _L()
+        if getattr(self, "_h", None):
+            torch.cuda.synchronize(self.device)
+            self.base.barrier()          # no peer may still be reading this rank's region
+            l.lc_p2p_comm_destroy(self._h)
+            self._h = None
+            for p in self._opened:
+                l.lc_p2p_close(p)
+            l.lc_p2p_free(self._own)
+
+
+def wrap_group_comm(comm: Optional[Comm], device, stage_bytes: int = DEFAULT_STAGE_BYTES) -> Optional[Comm]:
+    """The model-group communicator to hand to a sharded model: peer-to-peer kernels when the
+    group is 2, 4 or 8 ranks on GPUs (LC_P2P=0 keeps the bootstrap communicator)."""
+    if comm is None or comm.world == 1 or os.environ.get("LC_P2P", "1") != "1" or not supported(comm.world, device):
+        return comm
+    return P2PComm(comm, device, stage_bytes)
