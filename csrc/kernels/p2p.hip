@@ -115,12 +115,16 @@ LC_DEVICE void publish(const P2PPeers& peers, uint32_t flags_off, int rank, uint
 template <int W>
 LC_DEVICE bool wait_peers(char* self, uint32_t flags_off, int rank, uint32_t epoch, unsigned long long timeout,
                           int* shared_ok) {
-  if (threadIdx.x == 0) *shared_ok = 1;
+  // A communicator that has timed out once stays failed: later calls do not wait again (the
+  // host reads the error word after its next synchronisation and raises).
+  if (threadIdx.x == 0) *shared_ok = load_sys(&reinterpret_cast<Header*>(self)->error) == 0 ? 1 : 0;
   __syncthreads();
-  if (threadIdx.x < W && static_cast<int>(threadIdx.x) != rank) {
+  if (*shared_ok != 0 && threadIdx.x < W && static_cast<int>(threadIdx.x) != rank) {
     const uint32_t* f = reinterpret_cast<const uint32_t*>(self + flags_off) + threadIdx.x * kMaxBlocks + blockIdx.x;
     const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-    while (load_sys(f) != epoch) {
+    // flags only grow; "at least this call" (wrap-safe) also accepts a peer that publishes
+    // without consuming and therefore runs ahead (publish_only below)
+    while (static_cast<int32_t>(load_sys(f) - epoch) < 0) {
       __builtin_amdgcn_s_sleep(1);
       if (__builtin_amdgcn_s_memrealtime() - t0 > timeout) {
         store_sys(&reinterpret_cast<Header*>(self)->error, 1u + threadIdx.x);
@@ -155,6 +159,7 @@ struct ReduceArgs {
   int S, T, d, rank;
   float eps;
   unsigned long long timeout;
+  int publish_only;       // stage + flag the local rows, skip the wait and the reduction (y, h untouched)
 };
 
 // The local partial row chunk (8 elements) as fp32.
@@ -243,7 +248,7 @@ __global__ __launch_bounds__(kThreads, 4) void p2p_allreduce_kernel(P2PPeers pee
   }
   publish<W>(peers, reg.flags1, a.rank, epoch);
   // ---- consume
-  if (wait_peers<W>(self, reg.flags1, a.rank, epoch, a.timeout, &ok)) {
+  if (!a.publish_only && wait_peers<W>(self, reg.flags1, a.rank, epoch, a.timeout, &ok)) {
     for (int r = blockIdx.x; r < a.T; r += gridDim.x) {
       u32x4 raw[W][MAXC];
 #pragma unroll
@@ -357,6 +362,7 @@ struct ExchangeArgs {
   int nblk;          // 1: all-gather (everyone reads block 0 of every peer); W: all-to-all (rank q reads block q)
   int rank;
   unsigned long long timeout;
+  int publish_only;  // stage + flag only (see lc_p2p_allreduce)
 };
 
 // All-gather / equal-split all-to-all of raw bytes. Block b owns the 16-byte chunks j with
@@ -379,7 +385,7 @@ __global__ __launch_bounds__(kThreads) void p2p_exchange_kernel(P2PPeers peers, 
       }
   }
   publish<W>(peers, reg.flags1, a.rank, epoch);
-  if (wait_peers<W>(self, reg.flags1, a.rank, epoch, a.timeout, &ok)) {
+  if (!a.publish_only && wait_peers<W>(self, reg.flags1, a.rank, epoch, a.timeout, &ok)) {
     const uint32_t sel = a.nblk == 1 ? 0u : static_cast<uint32_t>(a.rank) * a.m;
 #pragma unroll
     for (int s = 0; s < W; ++s) {
@@ -435,7 +441,10 @@ LC_EXPORT int lc_p2p_alloc(long long bytes, void** ptr, void* handle_out) {
     e = hipExtMallocWithFlags(&p, static_cast<size_t>(bytes), hipDeviceMallocFinegrained);
   }
   if (e != hipSuccess) return static_cast<int>(e);
-  e = hipMemset(p, 0, static_cast<size_t>(bytes));
+  // Only the header and the flag arrays carry state between calls; the staging slots are
+  // written before they are read.
+  const size_t control = kHeaderBytes + 2 * static_cast<size_t>(kMaxRanks) * kMaxBlocks * 4;
+  e = hipMemset(p, 0, std::min(control, static_cast<size_t>(bytes)));
   if (e == hipSuccess) e = hipDeviceSynchronize();
   if (e == hipSuccess && handle_out != nullptr) {
     hipIpcMemHandle_t h;
@@ -500,14 +509,19 @@ LC_EXPORT long long lc_p2p_comm_capacity(void* comm) { return static_cast<CommSt
 // y = sum over ranks (h null). The local partial is either S fp32 slabs [S, T, d] (`part`) or a
 // bf16 [T, d] tensor (`xin`). two_shot selects the reduce-scatter + all-gather form. Every
 // rank must make the same call (same T, d, two_shot).
+// publish_only (one-shot form only) is for measurements where the peers of the rank under
+// test merely have to play their part of the protocol: they stage their rows, raise their
+// flags and leave, without waiting for anybody or holding a CU while they do.
 LC_EXPORT int lc_p2p_allreduce(void* comm, const void* part, int S, const void* xin, void* h, const void* w, void* y,
-                               int T, int d, float eps, int two_shot, hipStream_t stream) {
+                               int T, int d, float eps, int two_shot, int publish_only, hipStream_t stream) {
   CommState* c = static_cast<CommState*>(comm);
   if (T <= 0) return 0;
   if (d % 8 || d > 8 * kThreads * 8 || (part == nullptr) == (xin == nullptr) || (part && S < 1) || (h && !w)) return -1;
   if (static_cast<size_t>(T) * d * 2 > c->reg.stage_bytes) return -2;
   ReduceArgs a{static_cast<const float*>(part), static_cast<const bf16_t*>(xin), static_cast<bf16_t*>(h),
-               static_cast<const bf16_t*>(w), static_cast<bf16_t*>(y), S, T, d, c->rank, eps, c->timeout};
+               static_cast<const bf16_t*>(w), static_cast<bf16_t*>(y), S, T, d, c->rank, eps, c->timeout,
+               publish_only};
+  if (publish_only && two_shot) return -1;
   const dim3 grid(grid_for_rows(T)), block(kThreads);
   const int maxc = d <= 8 * kThreads ? 1 : (d <= 32 * kThreads ? 4 : 8);
 #define LC_LAUNCH1(W_, MAXC_) p2p_allreduce_kernel<W_, MAXC_><<<grid, block, 0, stream>>>(c->peers, c->reg, a)
@@ -533,13 +547,13 @@ LC_EXPORT int lc_p2p_allreduce(void* comm, const void* part, int S, const void* 
 // All-gather (nblk = 1: src holds m bytes, out world * m) or equal-split all-to-all (nblk =
 // world: src and out hold world blocks of m bytes). m must be a multiple of 16.
 LC_EXPORT int lc_p2p_exchange(void* comm, const void* src, void* out, long long m, int all_to_all,
-                              hipStream_t stream) {
+                              int publish_only, hipStream_t stream) {
   CommState* c = static_cast<CommState*>(comm);
   if (m <= 0) return 0;
   const int nblk = all_to_all ? c->world : 1;
   if (m % 16 || static_cast<size_t>(m) * nblk > c->reg.stage_bytes) return m % 16 ? -1 : -2;
   ExchangeArgs a{static_cast<const char*>(src), static_cast<char*>(out), static_cast<uint32_t>(m), nblk, c->rank,
-                 c->timeout};
+                 c->timeout, publish_only};
   const long long chunks = m / 16;
   const int blocks = static_cast<int>(std::max<long long>(1, std::min<long long>(kGridCap, (chunks + 1023) / 1024)));
   const dim3 grid(blocks), block(kThreads);

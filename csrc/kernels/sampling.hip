@@ -116,6 +116,9 @@ __global__ __launch_bounds__(kThreads) void sample_kernel(
   for (int i = 1; i < kWaves; ++i) am = argmax_combine(am, ArgMax{sv[i], si[i]});
   const float zmax = am.v;
   const float total = block_sum(run_m > -INFINITY ? run_s * __expf(run_m - zmax) : 0.f, red);
+  // A row without a single finite comparable entry (all NaN: a poisoned forward pass) leaves the
+  // arg-max index at its sentinel. It must never be used as an index or handed to the caller.
+  if (am.i < 0 || am.i >= V) am.i = 0;
   if (greedy) {
     if (threadIdx.x == 0) {
       out_token[r] = am.i;
@@ -310,7 +313,7 @@ __global__ __launch_bounds__(kThreads) void sample_kernel(
       }
       run += __shfl(incl, 63, 64);
     }
-    if (tok < 0) tok = last_kept >= 0 ? last_kept : am.i;
+    if (tok < 0 || tok >= V) tok = (last_kept >= 0 && last_kept < V) ? last_kept : am.i;
     if (lane == 0) {
       out_token[r] = tok;
       out_logprob[r] = (row[tok] * inv_t - zmax) - __logf(grand);

@@ -116,6 +116,10 @@ def build_backend(spec: ModelSpec, device: torch.device, comm=None, tp_rank: int
                  graph_buckets=spec.graph_batch_buckets, name=spec.name, mix_decode=spec.mix_decode,
                  optimistic_admission=spec.admission == "optimistic",
                  num_kv_blocks=spec.kv_blocks or (None if device.type == "cuda" else 512))
+    if grouped:
+        # Ranks of a group finish loading at different times; none of them may launch a step
+        # (its collectives wait for the peers with a timeout) before all of them are up.
+        comm.barrier()
     tok = make_tokenizer(spec.tokenizer, model.cfg.vocab_size)
     return EngineBackend(eng, tok, name=spec.name, stop_at_eos=spec.tokenizer is not None,
                          chat_format=spec.chat_format)

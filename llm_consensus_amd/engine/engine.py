@@ -529,6 +529,11 @@ class Engine:
                 self.metrics.inc("decode.steps")
                 self.metrics.inc("decode.tokens", len(plan.seq_ids))
                 self.metrics.inc("decode.seconds", time.perf_counter() - t0)
+            # A group collective that gave up waiting for a peer leaves garbage behind; the step's
+            # results must not be used (the error word is read once per step, after its sync).
+            check = getattr(self.model.comm, "check", None)
+            if check is not None:
+                check()
         self._collect()
 
     def step(self) -> bool:

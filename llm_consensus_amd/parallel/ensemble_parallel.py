@@ -150,7 +150,12 @@ class DistributedEnsemble:
         if lay.replica < 0:
             log.info("rank %d is idle under the placement plan", comm.rank)
             return
-        factory = backend_factory or (lambda spec, gc: build_backend(spec, self.device, gc, gc.rank))
+        from .p2p import wrap_group_comm
+
+        # A model group of 2, 4 or 8 GPUs talks through peer-to-peer kernels (one launch per
+        # collective, capturable); the process-group communicator only bootstraps it.
+        factory = backend_factory or (lambda spec, gc: build_backend(spec, self.device, wrap_group_comm(gc, self.device),
+                                                                     gc.rank))
         for name in sorted(lay.owners):
             local = factory(cfg.models[name], lay.hosted[name]) if name in lay.hosted else None
             self.backends[name] = ShardedBackend(name, local, lay.owners[name], lay.replica_comm)

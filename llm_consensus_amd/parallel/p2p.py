@@ -52,9 +52,9 @@ def _L():
         l.lc_p2p_comm_error.argtypes, l.lc_p2p_comm_error.restype = [c_void_p], c_int
         l.lc_p2p_comm_capacity.argtypes, l.lc_p2p_comm_capacity.restype = [c_void_p], c_longlong
         l.lc_p2p_allreduce.argtypes = [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
-                                       c_float, c_int, c_void_p]
+                                       c_float, c_int, c_int, c_void_p]
         l.lc_p2p_allreduce.restype = c_int
-        l.lc_p2p_exchange.argtypes = [c_void_p, c_void_p, c_void_p, c_longlong, c_int, c_void_p]
+        l.lc_p2p_exchange.argtypes = [c_void_p, c_void_p, c_void_p, c_longlong, c_int, c_int, c_void_p]
         l.lc_p2p_exchange.restype = c_int
         _lib = l
     return _lib
@@ -80,6 +80,11 @@ class P2PComm(Comm):
     construct it at the same point (collective)."""
 
     capturable = True
+
+    # Measurement aid: this rank only stages and flags its contribution to every all-reduce and
+    # never waits (see lc_p2p_allreduce); its own results are meaningless. Forces the one-shot form
+    # on THIS rank only, so set TWO_SHOT_BYTES high on the ranks under test too.
+    publish_only = False
 
     def __init__(self, base: Comm, device, stage_bytes: int = DEFAULT_STAGE_BYTES, timeout_s: float = TIMEOUT_S) -> None:
         if not supported(base.world, device):
@@ -135,7 +140,7 @@ class P2PComm(Comm):
         S = part.shape[0] if part is not None else 0
         for r0 in range(0, T, rows_cap):           # same split on every rank: capacity and shapes are equal
             n = min(rows_cap, T - r0)
-            two = 1 if n * d * 2 > TWO_SHOT_BYTES else 0
+            two = 1 if (n * d * 2 > TWO_SHOT_BYTES and not self.publish_only) else 0
             if part is not None and rows_cap < T:
                 # slabs of a row range are not contiguous across S: sum this range first
                 xr, pr = part[:, r0:r0 + n].sum(0).to(torch.bfloat16).contiguous(), None
@@ -144,7 +149,8 @@ class P2PComm(Comm):
             rc = l.lc_p2p_allreduce(
                 self._h, pr.data_ptr() if pr is not None else None, S if pr is not None else 0,
                 xr.data_ptr() if xr is not None else None, h[r0:r0 + n].data_ptr() if h is not None else None,
-                w.data_ptr() if w is not None else None, y[r0:r0 + n].data_ptr(), n, d, float(eps), two, self._stream())
+                w.data_ptr() if w is not None else None, y[r0:r0 + n].data_ptr(), n, d, float(eps), two,
+                1 if self.publish_only else 0, self._stream())
             self._check(rc, "lc_p2p_allreduce")
             self.calls += 1
 
@@ -193,7 +199,8 @@ class P2PComm(Comm):
             padded[:, :m] = raw
             raw = padded
         out = torch.empty(self.world, m_pad, dtype=torch.uint8, device=src.device)
-        rc = _L().lc_p2p_exchange(self._h, raw.data_ptr(), out.data_ptr(), m_pad, 1 if all_to_all else 0, self._stream())
+        rc = _L().lc_p2p_exchange(self._h, raw.data_ptr(), out.data_ptr(), m_pad, 1 if all_to_all else 0,
+                                  1 if self.publish_only else 0, self._stream())
         self._check(rc, "lc_p2p_exchange")
         self.calls += 1
         if m_pad != m:
