@@ -341,6 +341,7 @@ PYBIND11_MODULE(_core, m) {
       .def_property_readonly("num_running", &Scheduler::num_running)
       .def_property_readonly("num_preemptions", &Scheduler::num_preemptions)
       .def_property_readonly("num_head_skips", &Scheduler::num_head_skips)
+      .def("tokens_so_far", &Scheduler::tokens_so_far)
       .def("params_of", &Scheduler::params_of, py::return_value_policy::copy)
       .def("kind_of", &Scheduler::kind_of);
 

@@ -36,6 +36,14 @@ int Scheduler::add_request(RequestKind kind, std::vector<int32_t> prompt, int n_
   return id;
 }
 
+std::vector<std::vector<int32_t>> Scheduler::tokens_so_far(int request_id) const {
+  std::vector<std::vector<int32_t>> out;
+  auto it = groups_.find(request_id);
+  if (it == groups_.end() || !it->second.prefilled) return out;
+  for (const auto& c : it->second.chains) out.push_back(c.out);
+  return out;
+}
+
 const SamplingParams& Scheduler::params_of(int request_id) const { return groups_.at(request_id).p; }
 RequestKind Scheduler::kind_of(int request_id) const { return groups_.at(request_id).kind; }
 

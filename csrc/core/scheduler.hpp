@@ -152,6 +152,9 @@ class Scheduler {
   int num_running() const;
   int64_t num_preemptions() const { return preemptions_; }
   int64_t num_head_skips() const { return head_skips_total_; }
+  // Tokens generated so far by every chain of a request that is still running (empty when the
+  // request is unknown, waiting, or has just been preempted): what a streaming front end shows.
+  std::vector<std::vector<int32_t>> tokens_so_far(int request_id) const;
   const SamplingParams& params_of(int request_id) const;
   RequestKind kind_of(int request_id) const;
 

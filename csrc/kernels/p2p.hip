@@ -38,9 +38,11 @@
 // for another GPU, and blocks are dispatched in index order, so the lowest unfinished index of
 // every rank is always resident and the call progresses whatever the grid size. When several
 // ranks share ONE GPU (tests, or two small groups packed on a device) their waiting blocks
-// compete for the same slots, so all of them must fit at once: grids are capped at
-// kGridCap blocks (rows beyond that are walked by a block-stride loop), 8 ranks x 128 blocks
-// of 256 threads = the 1024 blocks a chip holds at four blocks per CU.
+// compete for the same slots, so all of them must fit at once: grids are capped (default
+// kGridCap blocks, rows beyond that are walked by a block-stride loop; 8 ranks x 128 blocks of
+// 256 threads = the 1024 blocks a chip holds at four blocks per CU). Ranks that share a GPU
+// with each other AND with kernels that need a whole CU (160 KiB of LDS, all registers of a
+// SIMD) should set the cap lower still, so that free CUs always remain (lc_p2p_comm_create).
 #include "common.h"
 
 #include <cstring>
@@ -403,6 +405,7 @@ struct CommState {
   P2PRegion reg;
   size_t region_bytes;
   unsigned long long timeout;
+  int grid_cap;
 };
 
 P2PRegion layout(uint32_t stage_bytes, uint32_t red_bytes, size_t* total) {
@@ -417,7 +420,7 @@ P2PRegion layout(uint32_t stage_bytes, uint32_t red_bytes, size_t* total) {
   return r;
 }
 
-int grid_for_rows(int T) { return std::max(1, std::min(T, kGridCap)); }
+int grid_for_rows(int T, int cap) { return std::max(1, std::min(T, cap)); }
 
 }  // namespace
 
@@ -473,7 +476,7 @@ LC_EXPORT int lc_p2p_handle_bytes() { return static_cast<int>(sizeof(hipIpcMemHa
 // all ranks' regions in THIS process (own allocation at index `rank`, peers through lc_p2p_open
 // or, for ranks that are threads of one process, the peers' own pointers).
 LC_EXPORT void* lc_p2p_comm_create(int world, int rank, void* const* bases, long long stage_bytes,
-                                   double timeout_s) {
+                                   double timeout_s, int grid_cap) {
   if ((world != 2 && world != 4 && world != 8) || rank < 0 || rank >= world) return nullptr;
   CommState* c = new CommState();
   c->world = world;
@@ -482,6 +485,7 @@ LC_EXPORT void* lc_p2p_comm_create(int world, int rank, void* const* bases, long
   const uint32_t sb = static_cast<uint32_t>((stage_bytes + 4095) / 4096 * 4096);
   c->reg = layout(sb, sb, &c->region_bytes);
   c->timeout = static_cast<unsigned long long>(timeout_s * 1e8);   // s_memrealtime ticks at 100 MHz
+  c->grid_cap = grid_cap > 0 ? std::min(grid_cap, kMaxBlocks) : kGridCap;
   return c;
 }
 
@@ -522,7 +526,7 @@ LC_EXPORT int lc_p2p_allreduce(void* comm, const void* part, int S, const void* 
                static_cast<const bf16_t*>(w), static_cast<bf16_t*>(y), S, T, d, c->rank, eps, c->timeout,
                publish_only};
   if (publish_only && two_shot) return -1;
-  const dim3 grid(grid_for_rows(T)), block(kThreads);
+  const dim3 grid(grid_for_rows(T, c->grid_cap)), block(kThreads);
   const int maxc = d <= 8 * kThreads ? 1 : (d <= 32 * kThreads ? 4 : 8);
 #define LC_LAUNCH1(W_, MAXC_) p2p_allreduce_kernel<W_, MAXC_><<<grid, block, 0, stream>>>(c->peers, c->reg, a)
 #define LC_LAUNCH2(W_, MAXC_) p2p_allreduce2_kernel<W_, MAXC_><<<grid, block, 0, stream>>>(c->peers, c->reg, a)
@@ -555,7 +559,7 @@ LC_EXPORT int lc_p2p_exchange(void* comm, const void* src, void* out, long long 
   ExchangeArgs a{static_cast<const char*>(src), static_cast<char*>(out), static_cast<uint32_t>(m), nblk, c->rank,
                  c->timeout, publish_only};
   const long long chunks = m / 16;
-  const int blocks = static_cast<int>(std::max<long long>(1, std::min<long long>(kGridCap, (chunks + 1023) / 1024)));
+  const int blocks = static_cast<int>(std::max<long long>(1, std::min<long long>(c->grid_cap, (chunks + 1023) / 1024)));
   const dim3 grid(blocks), block(kThreads);
 #define LC_LAUNCHX(W_, unused) p2p_exchange_kernel<W_><<<grid, block, 0, stream>>>(c->peers, c->reg, a)
   LC_P2P_BY_WORLD(LC_LAUNCHX, 0)

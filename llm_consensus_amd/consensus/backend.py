@@ -46,9 +46,12 @@ class GenResult:
 class Handle:
     """Result slot for one submitted request."""
 
-    __slots__ = ("_value", "_error", "_done", "submitted_at", "finished_at", "tag")
+    __slots__ = ("_value", "_error", "_done", "submitted_at", "finished_at", "tag", "usage")
 
     def __init__(self, tag: Any = None) -> None:
+        # (prompt tokens, completion tokens, prompt tokens served from the prefix cache) of the
+        # call, when the backend counts tokens; summed into ConsensusResult.usage
+        self.usage: Optional[tuple] = None
         self._value = None
         self._error: Optional[BaseException] = None
         self._done = False
@@ -85,7 +88,10 @@ class Backend:
 
     name = "backend"
 
-    def submit_generate(self, prompt: str, params: GenParams) -> Handle:
+    def submit_generate(self, prompt: str, params: GenParams, on_text: Optional[Callable[[int, str], None]] = None) -> Handle:
+        """``on_text(chain, new_text)``, where the backend supports it, is called from the
+        thread that drives the backend with every piece of text as it is generated (token
+        streaming); the handle still completes with the whole result."""
         raise NotImplementedError
 
     def submit_score(self, prompt: str, targets: Sequence[str]) -> Handle:
@@ -132,6 +138,19 @@ class Backend:
         return {}
 
 
+def add_usage(total: Dict[str, int], handles) -> Dict[str, int]:
+    """Adds the token counts of finished member calls to ``total`` (prompt_tokens,
+    completion_tokens, cached_tokens, total_tokens)."""
+    for h in handles:
+        u = getattr(h, "usage", None)
+        if u:
+            total["prompt_tokens"] = total.get("prompt_tokens", 0) + int(u[0])
+            total["completion_tokens"] = total.get("completion_tokens", 0) + int(u[1])
+            total["cached_tokens"] = total.get("cached_tokens", 0) + int(u[2])
+    total["total_tokens"] = total.get("prompt_tokens", 0) + total.get("completion_tokens", 0)
+    return total
+
+
 def run_backends(backends: Sequence["Backend"]) -> None:
     """Completes the submitted requests of several backends. Engines that live in this
     process are stepped together with their GPU work overlapped on separate streams; all
@@ -164,16 +183,21 @@ class CallableBackend(Backend):
         self.name = name
         self._queue: List[tuple] = []
 
-    def submit_generate(self, prompt: str, params: GenParams) -> Handle:
+    def submit_generate(self, prompt: str, params: GenParams, on_text=None) -> Handle:
         h = Handle()
-        self._queue.append((h, prompt, params))
+        self._queue.append((h, prompt, params, on_text))
         return h
 
     def run(self) -> None:
         q, self._queue = self._queue, []
-        for h, prompt, params in q:
+        for h, prompt, params, on_text in q:
             try:
-                h.set_result(GenResult(texts=[self.fn(prompt) for _ in range(max(1, params.n))]))
+                texts = [self.fn(prompt) for _ in range(max(1, params.n))]
+                if on_text is not None:
+                    for i, t in enumerate(texts):
+                        on_text(i, t)
+                h.usage = (len(prompt.split()), sum(len(t.split()) for t in texts), 0)
+                h.set_result(GenResult(texts=texts))
             except Exception as e:  # surfaced as a member failure, never a crash
                 h.set_error(e)
 
@@ -234,7 +258,7 @@ class ScriptedBackend(Backend):
             return "refined answer"
         return "proposed answer"
 
-    def submit_generate(self, prompt: str, params: GenParams) -> Handle:
+    def submit_generate(self, prompt: str, params: GenParams, on_text=None) -> Handle:
         h = Handle()
         self._queue.append(("gen", h, prompt, params))
         return h
@@ -275,14 +299,17 @@ class ScriptedBackend(Backend):
                     if extra.decision_targets:
                         fn = self.scores or (lambda p, t: [0.0] + [-1.0] * (len(t) - 1))
                         dec = [list(fn(prompt + x, extra.decision_targets)) for x in texts]
+                    h.usage = (len(prompt.split()), sum(len(t.split()) for t in texts), 0)   # words stand in for tokens
                     h.set_result(GenResult(texts=texts, decision_logprobs=dec))
                 elif kind == "score":
                     self.calls.append(("score", prompt))
                     fn = self.scores or (lambda p, t: [0.0] + [-1.0] * (len(t) - 1))
+                    h.usage = (len(prompt.split()), 0, 0)
                     h.set_result(list(fn(prompt, extra)))
                 else:
                     self.calls.append(("embed", prompt))
                     fn = self.embed or (lambda t: [float(len(t) % 7), 1.0, float(t.count("a"))])
+                    h.usage = (len(prompt.split()), 0, 0)
                     h.set_result(list(fn(prompt)))
             except Exception as e:
                 h.set_error(e)

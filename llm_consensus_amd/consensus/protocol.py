@@ -24,7 +24,7 @@ from typing import Dict, List, Optional, Sequence
 from .._native import core
 from ..utils.log import get_logger
 from ..utils.trace import instant, span
-from .backend import BackendError, Handle, run_backends
+from .backend import BackendError, Handle, add_usage, run_backends
 from .members import Member, distinct_backends
 
 log = get_logger("consensus.coordinator")
@@ -46,16 +46,18 @@ class ConsensusResult:
     votes: List[Dict] = field(default_factory=list)  # last round: [{member, verdict, reasoning}]
     transcript: List[Dict] = field(default_factory=list)
     extra: Dict = field(default_factory=dict)
+    usage: Dict[str, int] = field(default_factory=dict)   # tokens over all member calls of the question
 
     def to_json(self) -> str:
         return json.dumps(self.__dict__, default=str)
 
 
 class _Live:
-    __slots__ = ("session", "action", "t0", "handles", "index", "failed")
+    __slots__ = ("session", "action", "t0", "handles", "index", "failed", "usage")
 
     def __init__(self, session, action, index):
         self.session, self.action, self.index = session, action, index
+        self.usage: Dict[str, int] = {}
         self.t0 = time.perf_counter()
         self.handles: List[Handle] = []
         self.failed: Optional[str] = None
@@ -150,6 +152,7 @@ class Coordinator:
     def _collect(self, L: _Live) -> Optional[ConsensusResult]:
         """Feeds the completed member calls to the session. Returns the result when the
         session is finished, None when it has a next action to submit."""
+        add_usage(L.usage, L.handles)
         try:
             L.action = self._advance(L)
         except BackendError as e:
@@ -218,6 +221,7 @@ class Coordinator:
             agreement=(good / len(last_votes)) if last_votes else 0.0,
             votes=last_votes,
             transcript=tr,
+            usage=dict(L.usage),
         )
         if L.failed:
             res.extra["error"] = L.failed

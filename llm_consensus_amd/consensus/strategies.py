@@ -30,7 +30,7 @@ from .._native import core
 from ..utils.log import get_logger
 from ..utils.trace import span
 from . import reducers
-from .backend import BackendError, GenParams, run_backends
+from .backend import BackendError, GenParams, add_usage, run_backends
 from .members import Member, distinct_backends
 from .protocol import ConsensusResult
 
@@ -111,6 +111,7 @@ class MajorityVote:
                 agreement=float(red.agreement[r]),
                 votes=[{"member": m.name, "class": int(votes[r, i]), "text": texts[r][i]}
                        for i, m in enumerate(self.members)],
+                usage=add_usage({}, handles[r]),
             ))
         return out
 
@@ -190,6 +191,7 @@ class SelfConsistency:
                 agreement=float(red.agreement[r]),
                 votes=[{"chain": c, "class": int(votes[r, c])} for c in range(self.k)],
                 extra={"cached_prompt_tokens": cached[r], "chains": chains_text[r]},
+                usage=add_usage({}, [handles[r]]),
             ))
         return out
 
@@ -257,6 +259,7 @@ class JudgeLogprob:
                 latency_s=time.perf_counter() - t0,
                 votes=[{"candidate": self.proposers[c].name, "scores": scores[r, c].tolist()} for c in range(C)],
                 extra={"winner_score": float(red.score[r])},
+                usage=add_usage({}, list(prop[r]) + [h for row in score_h[r] for h in row]),
             ))
         return out
 
@@ -317,6 +320,7 @@ class EmbeddingMedoid:
                 latency_s=time.perf_counter() - t0, agreement=float(red.mean_pairwise),
                 votes=[{"candidate": owners[r][i], "text": c} for i, c in enumerate(cands[r])],
                 extra={"medoid_score": float(red.score)},
+                usage=add_usage({}, list(prop[r]) + list(emb_h[r])),
             ))
         return out
 

@@ -28,6 +28,7 @@ class EngineBackend(Backend):
         apply_chat_format(chat_format, "")        # validates the name
         self.chat_format = chat_format
         self._pending: Dict[int, tuple] = {}
+        self._streams: Dict[int, list] = {}
 
     def _params(self, p: GenParams) -> "core.SamplingParams":
         sp = core.SamplingParams()
@@ -43,13 +44,15 @@ class EngineBackend(Backend):
     def _wrap(self, prompt: str) -> str:
         return prompt if self.chat_format == "none" else apply_chat_format(self.chat_format, prompt)
 
-    def submit_generate(self, prompt: str, params: GenParams) -> Handle:
+    def submit_generate(self, prompt: str, params: GenParams, on_text=None) -> Handle:
         h = Handle()
         try:
             ids = self.tok.encode(self._wrap(prompt))
             dec = [self.tok.first_token_id(t) for t in params.decision_targets] if params.decision_targets else None
             rid = self.engine.submit(ids, core.RequestKind.Generate, max(1, params.n), self._params(params), dec)
             self._pending[rid] = ("gen", h)
+            if on_text is not None:
+                self._streams[rid] = [on_text, [""] * max(1, params.n)]   # callback, text already sent per chain
         except Exception as e:  # a bad request fails that member only
             h.set_error(e)
         return h
@@ -127,12 +130,37 @@ class EngineBackend(Backend):
             if not h.done:
                 h.set_error(BackendError(f"engine failure: {type(e).__name__}: {e}"))
         self._pending.clear()
+        self._streams.clear()
         try:
             self.engine.abort_all()
         except Exception as e2:  # noqa: BLE001
             log.error("%s: abort after failure failed too: %s", self.name, e2)
 
+    def _emit(self, rid: int, chains, final: bool) -> None:
+        """Streams what is new in ``chains`` (token lists) since the last call. Text is
+        decoded from the whole chain every time and only the stable part goes out: a trailing
+        replacement character is an unfinished multi-byte sequence, held back until it
+        completes (or the chain ends)."""
+        cb, sent = self._streams[rid]
+        eos = self.tok.eos_id
+        for i, toks in enumerate(chains):
+            if i >= len(sent):
+                break
+            if eos is not None and toks and toks[-1] == eos:
+                toks = toks[:-1]
+            text = self.tok.decode(toks)
+            if not final and text.endswith("\ufffd"):
+                text = text[:-1]            # an unfinished sequence decodes to ONE replacement character
+            if len(text) > len(sent[i]) and text.startswith(sent[i]):
+                cb(i, text[len(sent[i]):])
+                sent[i] = text
+
     def _harvest(self, final: bool) -> None:
+        for rid in list(self._streams):
+            if rid in self._pending:
+                chains = self.engine.sched.tokens_so_far(rid)
+                if chains:
+                    self._emit(rid, chains, final=False)
         for rid, (kind, h) in list(self._pending.items()):
             out = self.engine.pop_result(rid)
             if out is None:
@@ -141,6 +169,10 @@ class EngineBackend(Backend):
                     del self._pending[rid]
                 continue
             del self._pending[rid]
+            h.usage = (out.prompt_len, sum(len(t) for t in out.token_ids), out.cached_tokens)
+            if rid in self._streams:
+                self._emit(rid, out.token_ids, final=True)
+                del self._streams[rid]
             if kind == "gen":
                 eos = self.tok.eos_id
                 texts = []

@@ -52,8 +52,8 @@ class ShardedBackend(Backend):
         self._pending.append((h, inner))
         return h
 
-    def submit_generate(self, prompt: str, params: GenParams) -> Handle:
-        return self._submit("submit_generate", prompt, params)
+    def submit_generate(self, prompt: str, params: GenParams, on_text=None) -> Handle:
+        return self._submit("submit_generate", prompt, params)     # results arrive whole, after the exchange
 
     def submit_score(self, prompt: str, targets: Sequence[str]) -> Handle:
         return self._submit("submit_score", prompt, list(targets))
@@ -74,13 +74,14 @@ class ShardedBackend(Backend):
             payload = []
             for _, inner in pend:
                 try:
-                    payload.append(("ok", inner.result()))
+                    payload.append(("ok", inner.result(), inner.usage))
                 except BackendError as e:
-                    payload.append(("err", str(e)))
+                    payload.append(("err", str(e), None))
         if self.comm.world > 1:
             with span(f"publish:{self.name}", "parallel", requests=len(pend)):
                 payload = self.comm.broadcast_object(payload, self.owner)
-        for (h, _), (status, value) in zip(pend, payload):  # type: ignore[arg-type]
+        for (h, _), (status, value, usage) in zip(pend, payload):  # type: ignore[arg-type]
+            h.usage = usage
             if status == "ok":
                 h.set_result(value)
             else:

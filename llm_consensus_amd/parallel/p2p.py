@@ -46,7 +46,7 @@ def _L():
         l.lc_p2p_close.argtypes, l.lc_p2p_close.restype = [c_void_p], c_int
         l.lc_p2p_free.argtypes, l.lc_p2p_free.restype = [c_void_p], c_int
         l.lc_p2p_handle_bytes.argtypes, l.lc_p2p_handle_bytes.restype = [], c_int
-        l.lc_p2p_comm_create.argtypes = [c_int, c_int, ctypes.POINTER(c_void_p), c_longlong, c_double]
+        l.lc_p2p_comm_create.argtypes = [c_int, c_int, ctypes.POINTER(c_void_p), c_longlong, c_double, c_int]
         l.lc_p2p_comm_create.restype = c_void_p
         l.lc_p2p_comm_destroy.argtypes, l.lc_p2p_comm_destroy.restype = [c_void_p], None
         l.lc_p2p_comm_error.argtypes, l.lc_p2p_comm_error.restype = [c_void_p], c_int
@@ -64,6 +64,9 @@ def _L():
 TWO_SHOT_BYTES = int(os.environ.get("LC_P2P_TWO_SHOT_BYTES", str(1 << 20)))
 DEFAULT_STAGE_BYTES = int(os.environ.get("LC_P2P_STAGE_BYTES", str(64 << 20)))
 TIMEOUT_S = float(os.environ.get("LC_P2P_TIMEOUT_S", "20"))
+# Most blocks one collective launches (0 = the kernel library's default of 128). Lower it when
+# several ranks share one GPU (tests): waiting blocks hold CU slots.
+GRID_CAP = int(os.environ.get("LC_P2P_GRID_CAP", "0"))
 
 
 class P2PError(RuntimeError):
@@ -86,7 +89,8 @@ class P2PComm(Comm):
     # on THIS rank only, so set TWO_SHOT_BYTES high on the ranks under test too.
     publish_only = False
 
-    def __init__(self, base: Comm, device, stage_bytes: int = DEFAULT_STAGE_BYTES, timeout_s: float = TIMEOUT_S) -> None:
+    def __init__(self, base: Comm, device, stage_bytes: int = DEFAULT_STAGE_BYTES, timeout_s: float = TIMEOUT_S,
+                 grid_cap: int = GRID_CAP) -> None:
         if not supported(base.world, device):
             raise ValueError(f"P2PComm needs a CUDA device and 2, 4 or 8 ranks (got {base.world} on {device})")
         self.base, self.rank, self.world = base, base.rank, base.world
@@ -119,7 +123,7 @@ class P2PComm(Comm):
                                        "(HSA_ENABLE_IPC_MODE_LEGACY=0 must be set in every rank's environment)")
                     self._opened.append(q.value)
                     bases[r] = q.value
-            self._h = l.lc_p2p_comm_create(self.world, self.rank, bases, stage_bytes, timeout_s)
+            self._h = l.lc_p2p_comm_create(self.world, self.rank, bases, stage_bytes, timeout_s, grid_cap)
             if not self._h:
                 raise P2PError("lc_p2p_comm_create failed")
             self.capacity = int(l.lc_p2p_comm_capacity(self._h))

@@ -20,7 +20,10 @@ Routes
     POST /v1/chat/completions    model "consensus" (default) runs the configured strategy on
                                  the last user message; any other model name is served by
                                  that member model directly (n, max_tokens, temperature,
-                                 top_p, seed honoured). ``stream: true`` yields SSE chunks.
+                                 top_p, seed honoured). ``stream: true`` yields SSE chunks: one
+                                 per engine step for member models (tokens as they are
+                                 sampled), one for a consensus answer (it does not exist
+                                 before the vote is in).
     POST /v1/completions         same for a raw prompt
     POST /v1/embeddings          pooled, L2-normalised embeddings from a member model
 Consensus responses carry an extra ``consensus`` object (votes, rounds, agreement,
@@ -51,6 +54,8 @@ class _Job:
     text: str
     params: Optional[GenParams] = None
     done: threading.Event = field(default_factory=threading.Event)
+    # streaming requests: (chain, text) pieces as the engine produces them, None when finished
+    chunks: Optional["queue.Queue"] = None
     result: Any = None
     error: Optional[str] = None
     t_submit: float = field(default_factory=time.perf_counter)
@@ -175,10 +180,10 @@ class ConsensusServer:
                     else:
                         be = self.ensemble.backends[j.model]
                         direct.append((be.submit_embed(j.text) if j.kind == "embed"
-                                       else be.submit_generate(j.text, j.params), j))
+                                       else be.submit_generate(j.text, j.params, self._on_text(j)), j))
                 except Exception as e:  # noqa: BLE001
                     j.error = f"{type(e).__name__}: {e}"
-                    j.done.set()
+                    self._finish(j)
             try:
                 finished = pool.pump()
                 if not pool.active:          # nothing for the pool to step: direct requests only
@@ -189,7 +194,7 @@ class ConsensusServer:
                 log.error("engine step failed: %s", e)
                 for j in list(tickets.values()) + [j for _, j in direct]:
                     j.error = f"{type(e).__name__}: {e}"
-                    j.done.set()
+                    self._finish(j)
                 tickets.clear()
                 direct.clear()
                 pool = SessionPool(self.ensemble.strategy)
@@ -208,8 +213,20 @@ class ConsensusServer:
                     j.result = h.result()
                 except BackendError as e:
                     j.error = str(e)
-                j.done.set()
+                self._finish(j)
             direct = still
+
+    @staticmethod
+    def _on_text(j: _Job):
+        if j.chunks is None:
+            return None
+        return lambda chain, text: j.chunks.put((chain, text))
+
+    @staticmethod
+    def _finish(j: _Job) -> None:
+        j.done.set()
+        if j.chunks is not None:
+            j.chunks.put(None)
 
     def _drive(self) -> None:
         if self._continuous_ok():
@@ -229,7 +246,7 @@ class ConsensusServer:
                     if not j.done.is_set():
                         j.error = f"{type(e).__name__}: {e}"
             for j in batch:
-                j.done.set()
+                self._finish(j)
 
     def _run_batch(self, batch: List[_Job]) -> None:
         cons = [j for j in batch if j.kind == "consensus"]
@@ -240,9 +257,16 @@ class ConsensusServer:
         handles = []
         for j in direct:
             be = self.ensemble.backends[j.model]
-            handles.append(be.submit_embed(j.text) if j.kind == "embed" else be.submit_generate(j.text, j.params))
+            handles.append(be.submit_embed(j.text) if j.kind == "embed"
+                           else be.submit_generate(j.text, j.params, self._on_text(j)))
+        streaming = any(j.chunks is not None for j in direct)
         for name in {j.model for j in direct}:
-            self.ensemble.backends[name].run()
+            be = self.ensemble.backends[name]
+            if streaming and getattr(be, "incremental", False):
+                while be.poll():            # step by step, so streamed tokens leave as they are sampled
+                    pass
+            else:
+                be.run()
         for j, h in zip(direct, handles):
             try:
                 j.result = h.result()
@@ -374,14 +398,19 @@ class ConsensusServer:
             if not isinstance(text, str) or not text:
                 raise HTTPError(400, "'prompt' must be a non-empty string")
         params = self._gen_params(body)
-        job = self.submit(_Job("consensus" if consensus else "generate", model, text, params))
         rid = ("chatcmpl-" if chat else "cmpl-") + uuid.uuid4().hex[:24]
         created = int(time.time())
+        if body.get("stream") and not consensus:
+            return self._stream_tokens(h, rid, created, model, text, params, chat)
+        job = self.submit(_Job("consensus" if consensus else "generate", model, text, params))
         extra: Dict[str, Any] = {}
         if consensus:
             r = job.result
             texts = [r.answer]
-            usage = {"prompt_tokens": 0, "completion_tokens": 0, "total_tokens": 0}
+            u = getattr(r, "usage", None) or {}
+            usage = {"prompt_tokens": int(u.get("prompt_tokens", 0)), "completion_tokens": int(u.get("completion_tokens", 0)),
+                     "total_tokens": int(u.get("total_tokens", 0)),
+                     "prompt_tokens_details": {"cached_tokens": int(u.get("cached_tokens", 0))}}
             extra["consensus"] = {"strategy": r.strategy, "rounds": r.rounds, "member_calls": r.member_calls,
                                   "unanimous": r.unanimous, "forced": r.forced, "agreement": r.agreement,
                                   "proposer": r.proposer, "latency_s": r.latency_s, "votes": r.votes}
@@ -404,9 +433,60 @@ class ConsensusServer:
         self._send_json(h, 200, {"id": rid, "object": obj, "created": created, "model": model,
                                  "choices": choices, "usage": usage, **extra})
 
+    def _stream_tokens(self, h, rid, created, model, text, params, chat) -> None:
+        """Server-sent events of a member model's completion: the handler thread relays the
+        pieces of text the driver thread's engine steps produce (one chunk per step and chain),
+        then the stop chunks with the usage record."""
+        job = _Job("generate", model, text, params, chunks=queue.Queue())
+        self.jobs.put(job)
+        h.send_response(200)
+        h.send_header("Content-Type", "text/event-stream")
+        h.send_header("Cache-Control", "no-cache")
+        h.send_header("Connection", "close")
+        h.end_headers()
+        obj = "chat.completion.chunk" if chat else "text_completion"
+
+        def emit(choice, **more):
+            payload = {"id": rid, "object": obj, "created": created, "model": model, "choices": [choice], **more}
+            h.wfile.write(b"data: " + json.dumps(payload).encode() + b"\n\n")
+            h.wfile.flush()
+
+        started = set()
+        deadline = time.perf_counter() + self.request_timeout_s
+        while True:
+            try:
+                item = job.chunks.get(timeout=max(0.0, deadline - time.perf_counter()))
+            except queue.Empty:
+                emit({"index": 0, "delta": {}, "finish_reason": "error"}, error={"message": "request timed out"})
+                break
+            if item is None:
+                break
+            i, piece = item
+            if chat:
+                delta = {"content": piece}
+                if i not in started:
+                    delta["role"] = "assistant"
+                    started.add(i)
+                emit({"index": i, "delta": delta, "finish_reason": None})
+            else:
+                emit({"index": i, "text": piece, "finish_reason": None})
+        if job.error:
+            emit({"index": 0, "delta": {}, "finish_reason": "error"}, error={"message": job.error})
+        elif job.result is not None:
+            g = job.result
+            ct = sum(len(t) for t in g.token_ids)
+            usage = {"prompt_tokens": g.prompt_tokens, "completion_tokens": ct, "total_tokens": g.prompt_tokens + ct}
+            for i in range(len(g.texts)):
+                last = {"usage": usage} if i == len(g.texts) - 1 else {}
+                emit({"index": i, "delta": {}, "finish_reason": "stop"} if chat
+                     else {"index": i, "text": "", "finish_reason": "stop"}, **last)
+        h.wfile.write(b"data: [DONE]\n\n")
+        h.wfile.flush()
+        h.close_connection = True
+
     def _stream(self, h, rid, created, model, texts, chat, extra) -> None:
-        """Server-sent events. Answers are produced whole (a consensus answer does not exist
-        until the vote is in), so each choice is one content chunk followed by a stop chunk."""
+        """Server-sent events for answers that are produced whole (a consensus answer does not
+        exist until the vote is in): each choice is one content chunk followed by a stop chunk."""
         h.send_response(200)
         h.send_header("Content-Type", "text/event-stream")
         h.send_header("Cache-Control", "no-cache")

@@ -112,7 +112,7 @@ def main() -> None:
     progress("gloo up")
     rank, W = dist.get_rank(), dist.get_world_size()
     base = TorchDistComm(dist, torch.device("cpu"))
-    comm = p2p.P2PComm(base, DEV, stage_bytes=16 << 20, timeout_s=5)
+    comm = p2p.P2PComm(base, DEV, stage_bytes=16 << 20, timeout_s=5, grid_cap=32)   # the ranks share one GPU
     report = {"world": W}
     progress("regions mapped")
 
@@ -153,7 +153,7 @@ def main() -> None:
 
     progress("messages larger")
     # ---- messages larger than the staging slot are cut into row ranges
-    small = p2p.P2PComm(base, DEV, stage_bytes=64 << 10, timeout_s=5)
+    small = p2p.P2PComm(base, DEV, stage_bytes=64 << 10, timeout_s=5, grid_cap=32)
     check_allreduce(small, base, W, rank, 100, 1024, 0, "chunked bf16")
     check_allreduce(small, base, W, rank, 100, 1024, 2, "chunked slabs")
     small.close()

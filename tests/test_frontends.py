@@ -185,8 +185,30 @@ def test_http_member_model_completion_and_stream(server):
                     {"model": "m0", "stream": True, "max_tokens": 4, "messages": [{"role": "user", "content": "hi"}]})
     events = [l[6:] for l in raw.decode().splitlines() if l.startswith("data: ")]
     assert events[-1] == "[DONE]"
-    assert json.loads(events[0])["choices"][0]["delta"]["role"] == "assistant"
-    assert json.loads(events[1])["choices"][0]["finish_reason"] == "stop"
+    chunks = [json.loads(e) for e in events[:-1]]
+    assert chunks[0]["choices"][0]["delta"]["role"] == "assistant"
+    assert chunks[-1]["choices"][0]["finish_reason"] == "stop" and chunks[-1]["usage"]["completion_tokens"] == 4
+    # tokens leave as they are sampled: several content chunks, and together they are the completion
+    pieces = [c["choices"][0]["delta"].get("content", "") for c in chunks if c["choices"][0]["finish_reason"] is None]
+    assert len(pieces) >= 2
+    st, body = _post(server.port, "/v1/chat/completions",
+                     {"model": "m0", "max_tokens": 4, "messages": [{"role": "user", "content": "hi"}]})
+    assert "".join(pieces) == json.loads(body)["choices"][0]["message"]["content"]
+    # text-completion flavour of the same stream
+    st, raw = _post(server.port, "/v1/completions", {"model": "m1", "prompt": "hello", "max_tokens": 3, "stream": True})
+    ev = [json.loads(l[6:]) for l in raw.decode().splitlines() if l.startswith("data: ") and l != "data: [DONE]"]
+    assert ev[-1]["choices"][0]["finish_reason"] == "stop" and len(ev) >= 2
+
+
+def test_consensus_responses_report_token_usage(server, tiny_ensemble):
+    """Usage of a consensus answer = the tokens of every member call behind it."""
+    st, body = _post(server.port, "/v1/chat/completions",
+                     {"messages": [{"role": "user", "content": "Pick. A) a B) b C) c D) d"}]})
+    u = json.loads(body)["usage"]
+    assert u["prompt_tokens"] > 3 * 10 and u["completion_tokens"] > 0
+    assert u["total_tokens"] == u["prompt_tokens"] + u["completion_tokens"]
+    direct = tiny_ensemble.ask("Pick. A) a B) b C) c D) d")
+    assert direct.usage["prompt_tokens"] == u["prompt_tokens"]
 
 
 def test_http_embeddings(server):
@@ -244,3 +266,24 @@ def test_ensemble_metrics_sections(tiny_ensemble):
     assert c["latency_ms.count"] >= 2 and c["rounds.mean"] == 1.0 and 0 < c["agreement.mean"] <= 1
     assert any(k.startswith("decode_tokens_per_s.") for k in c)
     assert "kv.prefix_hit_rate" in st["m0"]
+
+
+def test_packaging_manifest_names_real_entry_points():
+    """pyproject.toml is this build's Cargo.toml (/root/reference/Cargo.toml:1-14): the console
+    scripts it declares must resolve to callables, and the build hook must know both native targets."""
+    import importlib
+
+    import tomli
+
+    root = CONFIGS.parent
+    meta = tomli.loads((root / "pyproject.toml").read_text())
+    assert meta["project"]["name"] == "llm-consensus-amd"
+    scripts = meta["project"]["scripts"]
+    assert set(scripts) == {"llm-consensus", "llm-consensus-serve", "llm-consensus-bench"}
+    for target in scripts.values():
+        mod, fn = target.split(":")
+        assert callable(getattr(importlib.import_module(mod), fn))
+    setup_src = (root / "setup.py").read_text()
+    assert "build_core" in setup_src and "build_kernels" in setup_src
+    # the package itself must be importable without the hyphenated compatibility link
+    assert importlib.import_module("llm_consensus_amd.workloads").make_questions

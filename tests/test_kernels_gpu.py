@@ -435,6 +435,25 @@ def test_sampler_matches_reference_definition(V):
     assert torch.allclose(lp.cpu()[m], wl[m], atol=2e-3)
 
 
+def test_sampler_never_returns_an_out_of_range_token_for_poisoned_rows():
+    """All-NaN and all -inf rows (what a failed forward pass leaves behind) have no arg-max; the
+    kernel must still hand back a token inside the vocabulary and must not index with a sentinel."""
+    V, R = 32000, 6
+    logits = rand(R, V, scale=2.0)
+    logits[1] = float("nan")
+    logits[3] = float("-inf")
+    logits[4, ::2] = float("nan")
+    temp = torch.tensor([0.8, 0.8, 0.0, 0.8, 0.8, 0.0])
+    top_p = torch.full((R,), 0.9)
+    seeds = torch.arange(R, dtype=torch.int64)
+    tok, lp = ops.sample(logits.to(DEV), temp.to(DEV), top_p.to(DEV), None, seeds.to(DEV), None)
+    torch.cuda.synchronize()
+    t = tok.cpu()
+    assert bool(((t >= 0) & (t < V)).all()), t
+    g, _ = ops.sample(logits[1:2].to(DEV), torch.zeros(1, device=DEV), None, None, seeds[:1].to(DEV), None)
+    assert 0 <= int(g[0]) < V
+
+
 def test_sampler_statistics_and_reproducibility():
     V, R = 64, 4096
     base = torch.tensor([2.0, 1.0, 0.5, 0.0] + [-4.0] * (V - 4))
