@@ -23,4 +23,26 @@ class BuildWithNative(build_py):
         super().run()
 
 
-setup(cmdclass={"build_py": BuildWithNative})
+def legacy_metadata() -> dict:
+    """setuptools before 61 ignores pyproject's [project] table: hand the same data to setup()."""
+    import setuptools
+
+    if int(setuptools.__version__.split(".")[0]) >= 61:
+        return {}
+    try:
+        import tomllib as toml
+    except ImportError:
+        import tomli as toml
+    from setuptools import find_packages
+
+    p = toml.loads((ROOT / "pyproject.toml").read_text())["project"]
+    return {
+        "name": p["name"], "version": p["version"], "description": p["description"],
+        "python_requires": p["requires-python"], "install_requires": p["dependencies"],
+        "packages": find_packages(include=["llm_consensus_amd*"]),
+        "package_data": {"llm_consensus_amd._native": ["*.so"]},
+        "entry_points": {"console_scripts": [f"{k} = {v}" for k, v in p["scripts"].items()]},
+    }
+
+
+setup(cmdclass={"build_py": BuildWithNative}, **legacy_metadata())
