@@ -39,8 +39,9 @@
 // every rank is always resident and the call progresses whatever the grid size. When several
 // ranks share ONE GPU (tests, or two small groups packed on a device) their waiting blocks
 // compete for the same slots, so all of them must fit at once: grids are capped (default
-// kGridCap blocks, rows beyond that are walked by a block-stride loop; 8 ranks x 128 blocks of
-// 256 threads = the 1024 blocks a chip holds at four blocks per CU). Ranks that share a GPU
+// kGridCap blocks, rows beyond that are walked by a block-stride loop; 8 ranks x 64 blocks of
+// 256 threads = the 512 blocks a chip holds at two blocks per CU, which is what the reduction
+// kernels' register budget admits). Ranks that share a GPU
 // with each other AND with kernels that need a whole CU (160 KiB of LDS, all registers of a
 // SIMD) should set the cap lower still, so that free CUs always remain (lc_p2p_comm_create).
 #include "common.h"
@@ -53,7 +54,7 @@ constexpr int kMaxRanks = 8;
 constexpr int kMaxBlocks = 1024;
 constexpr int kHeaderBytes = 256;
 constexpr int kThreads = 256;
-constexpr int kGridCap = 128;
+constexpr int kGridCap = 64;
 
 struct P2PRegion {   // byte offsets inside every rank's region (same on all ranks)
   uint32_t flags1, flags2, stage, red;
@@ -181,10 +182,32 @@ LC_DEVICE void local_chunk(const ReduceArgs& a, int r, int c, float* f) {
   }
 }
 
+// What the epilogue of a row needs besides the reduced delta: the residual row and the norm
+// weight. Loaded BEFORE the wait for the peers, so their latency overlaps the hand-off.
+template <int MAXC>
+struct RowOperands {
+  u32x4 h[MAXC], w[MAXC];
+};
+
+template <int MAXC>
+LC_DEVICE void load_row_operands(const ReduceArgs& a, int r, RowOperands<MAXC>& ro) {
+  if (a.h == nullptr) return;
+  const int nchunk = a.d >> 3;
+#pragma unroll
+  for (int k = 0; k < MAXC; ++k) {
+    const int c = threadIdx.x + k * kThreads;
+    if (c < nchunk) {
+      ro.h[k] = *reinterpret_cast<const u32x4*>(a.h + static_cast<size_t>(r) * a.d + c * 8);
+      ro.w[k] = *reinterpret_cast<const u32x4*>(a.w + c * 8);
+    }
+  }
+}
+
 // Residual add + RMSNorm of one row held as MAXC chunks per thread (acc = the all-reduced
 // delta). Writes h and y. `red` = 16 floats of LDS.
 template <int MAXC>
-LC_DEVICE void row_epilogue(const ReduceArgs& a, int r, float (&acc)[MAXC][8], float* red) {
+LC_DEVICE void row_epilogue(const ReduceArgs& a, int r, float (&acc)[MAXC][8], const RowOperands<MAXC>& ro,
+                            float* red) {
   const int nchunk = a.d >> 3;
   if (a.h == nullptr) {
 #pragma unroll
@@ -199,16 +222,15 @@ LC_DEVICE void row_epilogue(const ReduceArgs& a, int r, float (&acc)[MAXC][8], f
   for (int k = 0; k < MAXC; ++k) {
     const int c = threadIdx.x + k * kThreads;
     if (c < nchunk) {
-      bf16_t* hp = a.h + static_cast<size_t>(r) * a.d + c * 8;
       float hv[8];
-      unpack8(*reinterpret_cast<const u32x4*>(hp), hv);
+      unpack8(ro.h[k], hv);
       // the delta enters the residual stream rounded to bf16, as a stored all-reduce result would
       float dv[8];
       unpack8(pack8(acc[k]), dv);
 #pragma unroll
       for (int j = 0; j < 8; ++j) hv[j] += dv[j];
       const u32x4 packed = pack8(hv);
-      *reinterpret_cast<u32x4*>(hp) = packed;
+      *reinterpret_cast<u32x4*>(a.h + static_cast<size_t>(r) * a.d + c * 8) = packed;
       unpack8(packed, acc[k]);                       // normalise what was stored
 #pragma unroll
       for (int j = 0; j < 8; ++j) ss += acc[k][j] * acc[k][j];
@@ -221,7 +243,7 @@ LC_DEVICE void row_epilogue(const ReduceArgs& a, int r, float (&acc)[MAXC][8], f
     const int c = threadIdx.x + k * kThreads;
     if (c < nchunk) {
       float wv[8], o[8];
-      unpack8(*reinterpret_cast<const u32x4*>(a.w + c * 8), wv);
+      unpack8(ro.w[k], wv);
 #pragma unroll
       for (int j = 0; j < 8; ++j) o[j] = acc[k][j] * inv * wv[j];
       *reinterpret_cast<u32x4*>(a.y + static_cast<size_t>(r) * a.d + c * 8) = pack8(o);
@@ -231,13 +253,15 @@ LC_DEVICE void row_epilogue(const ReduceArgs& a, int r, float (&acc)[MAXC][8], f
 
 // One-shot all-reduce (+ residual + RMSNorm): every rank reads every peer's rows.
 template <int W, int MAXC>
-__global__ __launch_bounds__(kThreads, 4) void p2p_allreduce_kernel(P2PPeers peers, P2PRegion reg, ReduceArgs a) {
+__global__ __launch_bounds__(kThreads, 2) void p2p_allreduce_kernel(P2PPeers peers, P2PRegion reg, ReduceArgs a) {
   __shared__ float red[16];
   __shared__ int ok;
   char* self = peers.base[a.rank];
   const uint32_t epoch = reinterpret_cast<const Header*>(self)->epoch + 1;
   const uint32_t slot_off = reg.stage + (epoch & 1u) * reg.stage_bytes;
   const int nchunk = a.d >> 3;
+  RowOperands<MAXC> ro;
+  if (static_cast<int>(blockIdx.x) < a.T && !a.publish_only) load_row_operands<MAXC>(a, blockIdx.x, ro);
   // ---- publish this block's rows
   {
     const __amdgpu_buffer_rsrc_t mine = rsrc_of(self + slot_off, reg.stage_bytes);
@@ -252,6 +276,7 @@ __global__ __launch_bounds__(kThreads, 4) void p2p_allreduce_kernel(P2PPeers pee
   // ---- consume
   if (!a.publish_only && wait_peers<W>(self, reg.flags1, a.rank, epoch, a.timeout, &ok)) {
     for (int r = blockIdx.x; r < a.T; r += gridDim.x) {
+      if (r != static_cast<int>(blockIdx.x)) load_row_operands<MAXC>(a, r, ro);
       u32x4 raw[W][MAXC];
 #pragma unroll
       for (int s = 0; s < W; ++s) {
@@ -277,7 +302,7 @@ __global__ __launch_bounds__(kThreads, 4) void p2p_allreduce_kernel(P2PPeers pee
           }
         }
       }
-      row_epilogue<MAXC>(a, r, acc, red);
+      row_epilogue<MAXC>(a, r, acc, ro, red);
     }
   }
   finish_call(self, epoch);
@@ -288,7 +313,7 @@ __global__ __launch_bounds__(kThreads, 4) void p2p_allreduce_kernel(P2PPeers pee
 // rows it does not own (all-gather) and applies residual + norm to all rows. Per rank
 // 2 (W-1)/W of the message crosses the fabric instead of W-1 times.
 template <int W, int MAXC>
-__global__ __launch_bounds__(kThreads, 4) void p2p_allreduce2_kernel(P2PPeers peers, P2PRegion reg, ReduceArgs a) {
+__global__ __launch_bounds__(kThreads, 2) void p2p_allreduce2_kernel(P2PPeers peers, P2PRegion reg, ReduceArgs a) {
   __shared__ float red[16];
   __shared__ int ok;
   char* self = peers.base[a.rank];
@@ -340,6 +365,8 @@ __global__ __launch_bounds__(kThreads, 4) void p2p_allreduce2_kernel(P2PPeers pe
       const int owner = r / rpr;
       const __amdgpu_buffer_rsrc_t src = rsrc_of(peers.base[owner] + red_off, reg.red_bytes);
       const uint32_t row_off = static_cast<uint32_t>((static_cast<size_t>(r - owner * rpr) * a.d) * 2);
+      RowOperands<MAXC> ro;
+      load_row_operands<MAXC>(a, r, ro);
       float acc[MAXC][8];
 #pragma unroll
       for (int k = 0; k < MAXC; ++k) {
@@ -351,7 +378,7 @@ __global__ __launch_bounds__(kThreads, 4) void p2p_allreduce2_kernel(P2PPeers pe
           for (int j = 0; j < 8; ++j) acc[k][j] = 0.f;
         }
       }
-      row_epilogue<MAXC>(a, r, acc, red);
+      row_epilogue<MAXC>(a, r, acc, ro, red);
     }
   }
   finish_call(self, epoch);

@@ -85,6 +85,8 @@ class ConsensusConfig:
     forward_reasoning_to_refiner: bool = False
     k_chains: int = 16
     samples_per_member: int = 1       # embedding_medoid: candidates sampled per proposer and question
+    micro_batches: int = 2            # judge_logprob / embedding_medoid: parts of a question batch pipelined
+    #                                   through the two phases (1 = propose everything, then judge everything)
     choices: str = "ABCD"
     tie_break: str = "lowest_class"
     deadline_s: Optional[float] = None

@@ -43,6 +43,45 @@ def _run_all(members: Sequence[Member], phase: str = "generate") -> None:
         run_backends(backends)
 
 
+def _micro_batches(n: int, parts: int) -> List[range]:
+    """``n`` items cut into at most ``parts`` contiguous, near-equal, non-empty ranges."""
+    if n <= 0:
+        return []
+    parts = max(1, min(parts, n))
+    base, extra = divmod(n, parts)
+    out, lo = [], 0
+    for i in range(parts):
+        hi = lo + base + (1 if i < extra else 0)
+        out.append(range(lo, hi))
+        lo = hi
+    return out
+
+
+def _two_stage_pipeline(n: int, parts: int, stage1, members1: Sequence[Member], stage2, members2: Sequence[Member],
+                        names=("generate", "judge")) -> None:
+    """Software pipeline over micro-batches of the question batch. ``stage1(rng)`` queues the
+    first-stage member calls of the questions in ``rng`` (proposals); ``stage2(rng)`` reads
+    their results and queues the second-stage calls (judge scores, embeddings). While the
+    second-stage members work on micro-batch k, the first-stage members already generate
+    micro-batch k + 1: both sets of backends are driven by ONE run_backends call, so engines
+    on different GPUs (or on different streams of one GPU) are busy at the same time instead
+    of taking turns. With one part this is the plain two-phase schedule. The reference's loop
+    has the same propose -> evaluate shape (/root/reference/src/main.rs:229 then :250) but only
+    one question in flight, so nothing to overlap."""
+    batches = _micro_batches(n, parts)
+    if not batches:
+        return
+    stage1(batches[0])
+    _run_all(members1, names[0])
+    for k, rng in enumerate(batches):
+        stage2(rng)
+        if k + 1 < len(batches):
+            stage1(batches[k + 1])
+            _run_all(list(members2) + list(members1), f"{names[1]}[{k}]+{names[0]}[{k + 1}]")
+        else:
+            _run_all(members2, f"{names[1]}[{k}]")
+
+
 def _classify(text: str, decision_lp: Optional[List[float]], choices: str) -> int:
     if decision_lp is not None:
         return int(np.argmax(np.asarray(decision_lp, dtype=np.float32)))
@@ -204,13 +243,16 @@ class JudgeLogprob:
     JUDGE_TARGETS = [" Yes", " No"]
 
     def __init__(self, proposers: Sequence[Member], judges: Sequence[Member],
-                 params: Optional[GenParams] = None, device=None) -> None:
+                 params: Optional[GenParams] = None, device=None, micro_batches: int = 2) -> None:
+        """``micro_batches`` > 1 pipelines the two phases: judges score one part of the question
+        batch while the proposers generate the next (see _two_stage_pipeline)."""
         if not proposers or not judges:
             raise ValueError("JudgeLogprob needs proposers and at least one judge")
         self.proposers = list(proposers)
         self.judges = list(judges)
         self.params = params
         self.device = device
+        self.micro_batches = micro_batches
 
     @staticmethod
     def judge_prompt(question: str, candidate: str) -> str:
@@ -219,24 +261,33 @@ class JudgeLogprob:
 
     def ask_many(self, questions: Sequence[str]) -> List[ConsensusResult]:
         t0 = time.perf_counter()
-        prop = [[m.submit_propose(q, self.params) for m in self.proposers] for q in questions]
-        _run_all(self.proposers)
-        cands: List[List[str]] = []
-        for r in range(len(questions)):
-            row = []
-            for i, h in enumerate(prop[r]):
-                try:
-                    row.append(Member.finish_text(h))
-                except BackendError as e:
-                    log.error("%s failed: %s", self.proposers[i].name, e)
-                    row.append("")
-            cands.append(row)
-        score_h = [[[j.backend.submit_score(self.judge_prompt(q, c), self.JUDGE_TARGETS) for j in self.judges]
-                    for c in cands[r]] for r, q in enumerate(questions)]
-        _run_all(self.judges, "judge")
+        R = len(questions)
+        prop: List[list] = [[] for _ in range(R)]
+        cands: List[List[str]] = [[] for _ in range(R)]
+        score_h: List[list] = [[] for _ in range(R)]
+
+        def propose(rng) -> None:
+            for r in rng:
+                prop[r] = [m.submit_propose(questions[r], self.params) for m in self.proposers]
+
+        def judge(rng) -> None:
+            for r in rng:
+                row = []
+                for i, h in enumerate(prop[r]):
+                    try:
+                        row.append(Member.finish_text(h))
+                    except BackendError as e:
+                        log.error("%s failed: %s", self.proposers[i].name, e)
+                        row.append("")
+                cands[r] = row
+                score_h[r] = [[j.backend.submit_score(self.judge_prompt(questions[r], c), self.JUDGE_TARGETS)
+                               for j in self.judges] for c in row]
+
+        _two_stage_pipeline(R, self.micro_batches, propose, self.proposers, judge, self.judges)
         C, J = len(self.proposers), len(self.judges)
-        scores = np.full((len(questions), C, J), -1e30, dtype=np.float32)
-        for r in range(len(questions)):
+        scores = np.full((R, C, J), -1e30, dtype=np.float32)
+        done_at = [t0] * R
+        for r in range(R):
             for c in range(C):
                 if not cands[r][c]:
                     continue
@@ -247,6 +298,7 @@ class JudgeLogprob:
                     except BackendError as e:
                         log.error("%s failed to score: %s", self.judges[j].name, e)
                         scores[r, c, j] = 0.0
+                    done_at[r] = max(done_at[r], score_h[r][c][j].finished_at or t0)
         with span("reduce", "strategy"):
             red = reducers.judge_reduce_batch(scores, device=self.device)
         out = []
@@ -256,7 +308,7 @@ class JudgeLogprob:
                 question=q, answer=cands[r][w] if w >= 0 else "", strategy=self.name, rounds=1,
                 member_calls=C + C * J, unanimous=bool(red.unanimous[r]),
                 proposer=self.proposers[w].name if w >= 0 else None,
-                latency_s=time.perf_counter() - t0,
+                latency_s=(done_at[r] - t0) if done_at[r] > t0 else time.perf_counter() - t0,
                 votes=[{"candidate": self.proposers[c].name, "scores": scores[r, c].tolist()} for c in range(C)],
                 extra={"winner_score": float(red.score[r])},
                 usage=add_usage({}, list(prop[r]) + [h for row in score_h[r] for h in row]),
@@ -271,7 +323,8 @@ class EmbeddingMedoid:
     name = "embedding_medoid"
 
     def __init__(self, proposers: Sequence[Member], embedder: Member,
-                 params: Optional[GenParams] = None, samples_per_member: int = 1, device=None) -> None:
+                 params: Optional[GenParams] = None, samples_per_member: int = 1, device=None,
+                 micro_batches: int = 2) -> None:
         if not proposers:
             raise ValueError("EmbeddingMedoid needs proposers")
         self.proposers = list(proposers)
@@ -279,34 +332,39 @@ class EmbeddingMedoid:
         self.params = params
         self.samples = samples_per_member
         self.device = device
+        self.micro_batches = micro_batches
 
     def ask_many(self, questions: Sequence[str]) -> List[ConsensusResult]:
         t0 = time.perf_counter()
-        prop = []
-        for q in questions:
-            row = []
-            for m in self.proposers:
-                p = self.params or m.params
-                if self.samples > 1:
-                    p = GenParams(**{**p.__dict__, "n": self.samples})
-                row.append(m.submit_propose(q, p))
-            prop.append(row)
-        _run_all(self.proposers)
-        cands: List[List[str]] = []
-        owners: List[List[str]] = []
-        for r in range(len(questions)):
-            row, own = [], []
-            for i, h in enumerate(prop[r]):
-                try:
-                    for t in h.result().texts:
-                        row.append(t)
-                        own.append(self.proposers[i].name)
-                except BackendError as e:
-                    log.error("%s failed: %s", self.proposers[i].name, e)
-            cands.append(row)
-            owners.append(own)
-        emb_h = [[self.embedder.backend.submit_embed(c) for c in cands[r]] for r in range(len(questions))]
-        _run_all([self.embedder], "embed")
+        R = len(questions)
+        prop: List[list] = [[] for _ in range(R)]
+        cands: List[List[str]] = [[] for _ in range(R)]
+        owners: List[List[str]] = [[] for _ in range(R)]
+        emb_h: List[list] = [[] for _ in range(R)]
+
+        def propose(rng) -> None:
+            for r in rng:
+                row = []
+                for m in self.proposers:
+                    p = self.params or m.params
+                    if self.samples > 1:
+                        p = GenParams(**{**p.__dict__, "n": self.samples})
+                    row.append(m.submit_propose(questions[r], p))
+                prop[r] = row
+
+        def embed(rng) -> None:
+            for r in rng:
+                for i, h in enumerate(prop[r]):
+                    try:
+                        for t in h.result().texts:
+                            cands[r].append(t)
+                            owners[r].append(self.proposers[i].name)
+                    except BackendError as e:
+                        log.error("%s failed: %s", self.proposers[i].name, e)
+                emb_h[r] = [self.embedder.backend.submit_embed(c) for c in cands[r]]
+
+        _two_stage_pipeline(R, self.micro_batches, propose, self.proposers, embed, [self.embedder],
+                            names=("generate", "embed"))
         out = []
         for r, q in enumerate(questions):
             if not cands[r]:
@@ -314,10 +372,11 @@ class EmbeddingMedoid:
                 continue
             E = np.stack([np.asarray(h.result(), dtype=np.float32) for h in emb_h[r]])
             red = reducers.cosine_medoid(E, device=self.device)
+            done = max((h.finished_at or t0) for h in emb_h[r])
             out.append(ConsensusResult(
                 question=q, answer=cands[r][red.index], strategy=self.name, rounds=1,
                 member_calls=len(self.proposers) + len(cands[r]), proposer=owners[r][red.index],
-                latency_s=time.perf_counter() - t0, agreement=float(red.mean_pairwise),
+                latency_s=(done - t0) if done > t0 else time.perf_counter() - t0, agreement=float(red.mean_pairwise),
                 votes=[{"candidate": owners[r][i], "text": c} for i, c in enumerate(cands[r])],
                 extra={"medoid_score": float(red.score)},
                 usage=add_usage({}, list(prop[r]) + list(emb_h[r])),

@@ -42,45 +42,78 @@ class ShardedBackend(Backend):
     """Replica-wide facade of one model. ``local`` is the engine backend on ranks that host
     the model (None elsewhere); ``owner`` is the replica rank that publishes results."""
 
-    def __init__(self, name: str, local: Optional[Backend], owner: int, comm: Comm) -> None:
+    def __init__(self, name: str, local: Optional[Backend], owner: int, comm: Comm, embed_dim: int = 0,
+                 device: Optional[torch.device] = None) -> None:
         self.name, self.local, self.owner, self.comm = name, local, owner, comm
-        self._pending: List[tuple] = []
+        self.embed_dim = embed_dim           # width of an embedding row (0: embeddings travel as objects)
+        self.device = device or torch.device("cpu")
+        self._pending: List[tuple] = []      # (handle, inner handle | None, numeric width | 0)
 
-    def _submit(self, method: str, *args) -> Handle:
+    def _submit(self, method: str, *args, width: int = 0) -> Handle:
         h = Handle()
         inner = getattr(self.local, method)(*args) if self.local is not None else None
-        self._pending.append((h, inner))
+        self._pending.append((h, inner, width))
         return h
 
     def submit_generate(self, prompt: str, params: GenParams, on_text=None) -> Handle:
         return self._submit("submit_generate", prompt, params)     # results arrive whole, after the exchange
 
     def submit_score(self, prompt: str, targets: Sequence[str]) -> Handle:
-        return self._submit("submit_score", prompt, list(targets))
+        return self._submit("submit_score", prompt, list(targets), width=len(targets))
 
     def submit_embed(self, text: str) -> Handle:
-        return self._submit("submit_embed", text)
+        return self._submit("submit_embed", text, width=self.embed_dim)
 
     def run_local(self) -> None:
         if self.local is not None and self._pending:
             self.local.run()
 
     def sync(self) -> None:
+        """Publishes the results of the queued calls to every rank of the replica. Log-prob
+        scores and embeddings are rows of numbers whose widths every rank knows, so they travel
+        as ONE float32 tensor broadcast on the communicator's own transport (device memory under
+        RCCL): columns [0, width) hold the row, the next three the token usage, the last one a
+        status flag. Generated text, and the message of a failed call, go through one host-object
+        broadcast; a phase that only scored or embedded sends no pickled payload at all."""
         pend, self._pending = self._pending, []
         if not pend:
             return
-        payload: Optional[List[tuple]] = None
-        if self.comm.rank == self.owner:
-            payload = []
-            for _, inner in pend:
+        mine = self.comm.rank == self.owner
+        numeric = [i for i, (_, _, w) in enumerate(pend) if w > 0]
+        objects = [i for i, (_, _, w) in enumerate(pend) if w <= 0]
+        results: List[Optional[tuple]] = [None] * len(pend)
+        if mine:
+            for i, (_, inner, _) in enumerate(pend):
                 try:
-                    payload.append(("ok", inner.result(), inner.usage))
+                    results[i] = ("ok", inner.result(), inner.usage)
                 except BackendError as e:
-                    payload.append(("err", str(e), None))
+                    results[i] = ("err", str(e), None)
         if self.comm.world > 1:
             with span(f"publish:{self.name}", "parallel", requests=len(pend)):
-                payload = self.comm.broadcast_object(payload, self.owner)
-        for (h, _), (status, value, usage) in zip(pend, payload):  # type: ignore[arg-type]
+                if numeric:
+                    wmax = max(pend[i][2] for i in numeric)
+                    table = torch.zeros(len(numeric), wmax + 4, dtype=torch.float32)
+                    if mine:
+                        for row, i in enumerate(numeric):
+                            status, value, usage = results[i]
+                            if status == "ok":
+                                table[row, :pend[i][2]] = torch.as_tensor(value, dtype=torch.float32).reshape(-1)
+                                table[row, wmax:wmax + 3] = torch.tensor([float(u) for u in (usage or (0, 0, 0))])
+                                table[row, wmax + 3] = 1.0
+                    table = self.comm.broadcast(table.to(self.device), self.owner).cpu()
+                    failed = [i for row, i in enumerate(numeric) if table[row, wmax + 3] == 0]
+                    for row, i in enumerate(numeric):
+                        if table[row, wmax + 3] != 0:
+                            usage = tuple(int(u) for u in table[row, wmax:wmax + 3].tolist())
+                            results[i] = ("ok", table[row, :pend[i][2]].numpy().copy(), usage)
+                else:
+                    failed = []
+                rest = objects + failed
+                if rest:
+                    payload = self.comm.broadcast_object([results[i] for i in rest] if mine else None, self.owner)
+                    for i, r in zip(rest, payload):
+                        results[i] = r
+        for (h, _, _), (status, value, usage) in zip(pend, results):  # type: ignore[misc]
             h.usage = usage
             if status == "ok":
                 h.set_result(value)
@@ -139,7 +172,7 @@ class DistributedEnsemble:
 
     def __init__(self, cfg, comm: Comm, device: Optional[torch.device] = None, plan=None,
                  backend_factory=None) -> None:
-        from ..app import build_backend, make_members, make_strategy
+        from ..app import build_backend, make_members, make_strategy, model_config_of
 
         self.config, self.comm = cfg, comm
         self.device = device or (torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available()
@@ -159,7 +192,9 @@ class DistributedEnsemble:
                                                                      gc.rank))
         for name in sorted(lay.owners):
             local = factory(cfg.models[name], lay.hosted[name]) if name in lay.hosted else None
-            self.backends[name] = ShardedBackend(name, local, lay.owners[name], lay.replica_comm)
+            self.backends[name] = ShardedBackend(name, local, lay.owners[name], lay.replica_comm,
+                                                 embed_dim=model_config_of(cfg.models[name]).hidden_size,
+                                                 device=self.device)
         self.members = make_members(cfg, self.backends)
         self.strategy = make_strategy(cfg, self.members, self.device)
 

@@ -64,7 +64,7 @@ def _L():
 TWO_SHOT_BYTES = int(os.environ.get("LC_P2P_TWO_SHOT_BYTES", str(1 << 20)))
 DEFAULT_STAGE_BYTES = int(os.environ.get("LC_P2P_STAGE_BYTES", str(64 << 20)))
 TIMEOUT_S = float(os.environ.get("LC_P2P_TIMEOUT_S", "20"))
-# Most blocks one collective launches (0 = the kernel library's default of 128). Lower it when
+# Most blocks one collective launches (0 = the kernel library's default of 64). Lower it when
 # several ranks share one GPU (tests): waiting blocks hold CU slots.
 GRID_CAP = int(os.environ.get("LC_P2P_GRID_CAP", "0"))
 

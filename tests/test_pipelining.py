@@ -1,0 +1,74 @@
+"""Phase pipelining of the two-phase strategies: judges (or the embedder) work on one part of a
+question batch while the proposers generate the next, and the answers are those of the serial
+schedule."""
+import dataclasses
+
+import pytest
+import torch
+
+from llm_consensus_amd.app import build_ensemble
+from llm_consensus_amd.config import ConsensusConfig, MemberConfig, ModelSpec, SamplingConfig
+from llm_consensus_amd.consensus.strategies import _micro_batches
+from llm_consensus_amd.utils.trace import TRACER
+
+CPU = torch.device("cpu")
+QUESTIONS = [f"Question {i}: pick one. A) a B) b C) c D) d" for i in range(6)]
+
+
+def two_phase_config(strategy: str, micro_batches: int) -> ConsensusConfig:
+    models = {"p0": ModelSpec(name="p0", preset="tiny-llama", seed=1),
+              "p1": ModelSpec(name="p1", preset="tiny-qwen", seed=2),
+              "second": ModelSpec(name="second", preset="tiny-mistral", seed=3)}
+    role = "judge" if strategy == "judge_logprob" else "embedder"
+    members = [MemberConfig(name="p0", model="p0"), MemberConfig(name="p1", model="p1"),
+               MemberConfig(name="second", model="second", role=role)]
+    return ConsensusConfig(strategy=strategy, models=models, members=members, micro_batches=micro_batches,
+                           sampling=SamplingConfig(temperature=0.0, max_new_tokens=6))
+
+
+def engine_spans():
+    return sorted(((e["ts"], e["ts"] + e["dur"], e["name"].split(".")[0]) for e in TRACER.events
+                   if e.get("cat") == "engine"), key=lambda s: s[0])
+
+
+def run_traced(strategy: str, micro_batches: int):
+    ens = build_ensemble(two_phase_config(strategy, micro_batches), CPU)
+    TRACER.clear()
+    TRACER.enable(roctx=False)
+    try:
+        res = ens.ask_many(QUESTIONS)
+        spans = engine_spans()
+    finally:
+        TRACER.disable()
+        TRACER.clear()
+    return res, spans
+
+
+def test_micro_batches_cover_every_question_once():
+    assert [list(r) for r in _micro_batches(5, 2)] == [[0, 1, 2], [3, 4]]
+    assert [list(r) for r in _micro_batches(2, 4)] == [[0], [1]]
+    assert _micro_batches(0, 2) == []
+
+
+@pytest.mark.parametrize("strategy", ["judge_logprob", "embedding_medoid"])
+def test_pipelined_schedule_overlaps_phases_and_keeps_the_answers(strategy):
+    serial, s_spans = run_traced(strategy, 1)
+    piped, p_spans = run_traced(strategy, 3)
+    assert [r.answer for r in piped] == [r.answer for r in serial]
+    assert [r.proposer for r in piped] == [r.proposer for r in serial]
+    for a, b in zip(piped, serial):
+        assert a.usage == b.usage
+
+    def interleaved(spans):
+        """The second-stage engine has work between two steps of a proposer engine."""
+        first_second = min(t0 for t0, _, n in spans if n == "second")
+        last_proposer = max(t1 for _, t1, n in spans if n in ("p0", "p1"))
+        return first_second < last_proposer
+
+    assert not interleaved(s_spans)            # serial: every proposal before the first score
+    assert interleaved(p_spans)
+    # One run_backends call drives both stages: within the window in which the second-stage
+    # engine works on part k, the proposer engines step too.
+    window = [(t0, t1) for t0, t1, n in p_spans if n == "second"]
+    lo, hi = window[0][0], window[-1][1]
+    assert sum(1 for t0, _, n in p_spans if n in ("p0", "p1") and lo < t0 < hi) >= 2
