@@ -69,6 +69,8 @@ def parse_args(argv=None):
     ap.add_argument("--sc-questions", type=int, default=16, help="questions per GPU per step (workload B)")
     ap.add_argument("--sc-steps", type=int, default=None, help="timed steps of workload B (default: --steps)")
     ap.add_argument("--skip-stream", action="store_true", help="skip the standing-queue run of workload A")
+    ap.add_argument("--in-flight", type=int, default=0,
+                    help="questions kept in flight per GPU in the standing-queue run (default 4 x --questions)")
     ap.add_argument("--aux-steps", type=int, default=None, help="timed steps of C, D, E (default: min(steps, 6))")
     ap.add_argument("--proto-questions", type=int, default=8, help="questions per GPU per step (workload C)")
     ap.add_argument("--proto-prompt-len", type=int, default=128)
@@ -247,7 +249,8 @@ def run_replica_workloads(ctx: Ctx, out: dict) -> None:
         names = names[:1]                                       # B and C run on the first model only
     seq_len = a.prompt_len + a.new_tokens
     blocks_per_seq = (seq_len + bs - 1) // bs + 1
-    max_seqs = max(a.questions if "A" in wl else 1, a.sc_questions * a.k_chains if "B" in wl else 1)
+    max_seqs = max(a.questions if "A" in wl else 1, a.sc_questions * a.k_chains if "B" in wl else 1,
+                   (a.in_flight or 4 * a.questions) if ("A" in wl and not a.skip_stream) else 1)
     t_init = time.perf_counter()
     members = []
     personas = core.default_personas()
@@ -287,25 +290,41 @@ def run_replica_workloads(ctx: Ctx, out: dict) -> None:
                                  "decode.wait_seconds", "prefill.rider_tokens")}
             for i in range(len(names))}
         if not a.skip_stream:
-            # The same ensemble under a standing queue: the questions of all timed steps are
-            # submitted together. Prompts are admitted as KV blocks and batch slots free up and the
-            # chains already decoding ride along in the steps that prefill them, so early
-            # questions finish early: p50 is about half the time of the whole queue.
-            def stream(n_total):
+            # The same ensemble as a service under load: a closed loop keeps ``in_flight``
+            # questions in the engines at all times; every finished question is replaced by a new
+            # one at the next engine step (strategies.VotePool). Prompts are admitted as KV blocks
+            # and batch slots free up, chains already decoding ride along in the steps that
+            # prefill the newcomers, and each member's decode batch stays at ~in_flight rows
+            # instead of draining at the end of every batch. The clock covers ramp-up and drain.
+            def closed_loop(n_total, in_flight):
+                qs = make_questions(rng, n_total, a.prompt_len)
+                pool = vote.pool()
                 comm.barrier()
                 ctx.sync()
                 t0 = time.perf_counter()
-                res = vote.ask_many(make_questions(rng, n_total, a.prompt_len))
+                res, nxt = [], 0
+                while nxt < min(in_flight, n_total):
+                    pool.submit(qs[nxt])
+                    nxt += 1
+                while pool.active:
+                    for _, r in pool.pump():
+                        res.append(r)
+                        if nxt < n_total:
+                            pool.submit(qs[nxt])
+                            nxt += 1
                 k = winners(res)
                 ctx.sync()
                 comm.barrier()
                 return comm.max_float(time.perf_counter() - t0), k, comm.gather_floats([r.latency_s * 1e3 for r in res])
 
-            stream(a.questions * max(1, a.warmup))
-            el_s, n_s, lat_s = stream(a.questions * a.steps)
+            inflight = a.in_flight or 4 * a.questions
+            closed_loop(inflight, inflight)
+            n_sq = inflight * max(2, min(a.steps, 4))
+            el_s, n_s, lat_s = closed_loop(n_sq, inflight)
             out["standing_queue"] = {
-                "questions_in_flight_per_gpu": a.questions * a.steps, "value": round(n_s / el_s, 3),
-                "unit": "answers/s", "ms_per_batch_of_questions": round(el_s / a.steps * 1e3, 2),
+                "mode": "closed loop: a finished question is replaced at the next engine step",
+                "questions_in_flight_per_gpu": inflight, "questions_per_gpu": n_sq, "value": round(n_s / el_s, 3),
+                "unit": "answers/s", "ms_per_batch_of_questions": round(el_s / n_sq * a.questions * 1e3, 2),
                 "p50_latency_ms": pct(lat_s, 50), "p95_latency_ms": pct(lat_s, 95),
                 "preemptions": int(sum(m.backend.stats().get("sched.preemptions", 0) for m in members)),
             }

@@ -175,6 +175,43 @@ def run_backends(backends: Sequence["Backend"]) -> None:
         b.sync()
 
 
+class BackendStepper:
+    """Advances a set of backends a little at a time, for drivers that admit new work between
+    increments (SessionPool, VotePool, the HTTP server). Engines that live in this process are
+    stepped through one EngineDriver, so their steps overlap on their own streams and prefills
+    take turns exactly as in run_backends; other backends get ``poll()``."""
+
+    def __init__(self, backends: Sequence["Backend"]) -> None:
+        self.backends = list(backends)
+        self._driver = None
+
+    def step(self) -> bool:
+        """One increment. Returns False when nothing moved (work in flight is still running)."""
+        inc = [b for b in self.backends if b.incremental]
+        pairs = [(b, e) for b in inc for e in b.engines()]
+        moved = False
+        if pairs:
+            if self._driver is None:
+                from ..engine.engine import EngineDriver
+
+                self._driver = EngineDriver()
+            owners = list({id(b): b for b, _ in pairs}.values())
+            try:
+                moved = self._driver.advance([e for _, e in pairs])
+            except Exception as err:  # noqa: BLE001  interleaved steps: none can be trusted after a failure
+                self._driver.reset()
+                for b in owners:
+                    b.fail_pending(err)
+                moved = True
+            for b in owners:
+                b.harvest()
+        for b in self.backends:
+            if not b.incremental:
+                b.poll()
+                moved = True
+        return moved
+
+
 class CallableBackend(Backend):
     """Wraps ``fn(prompt) -> str``; generation only."""
 

@@ -24,7 +24,7 @@ from typing import Dict, List, Optional, Sequence
 from .._native import core
 from ..utils.log import get_logger
 from ..utils.trace import instant, span
-from .backend import BackendError, Handle, add_usage, run_backends
+from .backend import BackendError, BackendStepper, Handle, add_usage, run_backends
 from .members import Member, distinct_backends
 
 log = get_logger("consensus.coordinator")
@@ -89,6 +89,10 @@ class Coordinator:
         return True
 
     # ------------------------------------------------------------------
+    def pool(self) -> "SessionPool":
+        """The driver without batch boundaries (same interface as strategies.VotePool)."""
+        return SessionPool(self)
+
     def ask(self, question: str) -> ConsensusResult:
         return self.ask_many([question])[0]
 
@@ -243,6 +247,7 @@ class SessionPool:
     def __init__(self, coordinator: Coordinator) -> None:
         self.c = coordinator
         self.backends = distinct_backends(coordinator.members)
+        self.stepper = BackendStepper(self.backends)
         self.live: Dict[int, _Live] = {}
         self._next = 0
 
@@ -276,25 +281,8 @@ class SessionPool:
                 del self.live[t]
             else:
                 self.c._submit(L)
-        stepping = [(b, e) for b in self.backends if b.incremental for e in b.engines() if e.has_work()]
-        if len(stepping) > 1:
-            # steps of different members' engines overlap on their own streams
-            owners = {id(b): b for b, _ in stepping}.values()
-            try:
-                tokens = [(b, e, e.begin_step()) for b, e in stepping]
-                for b, e, tok in tokens:
-                    if tok is not None:
-                        e.end_step(tok)
-            except Exception as err:  # noqa: BLE001  interleaved steps: none can be trusted after a failure
-                for b in owners:
-                    b.fail_pending(err)
-            for b in owners:
-                b.harvest()
-            rest = [b for b in self.backends if not b.incremental]
-        else:
-            rest = self.backends
-        for b in rest:
-            b.poll()
+        if not self.stepper.step() and not finished:
+            time.sleep(20e-6)
         return finished
 
     def drain(self) -> List[tuple]:

@@ -30,7 +30,7 @@ from .._native import core
 from ..utils.log import get_logger
 from ..utils.trace import span
 from . import reducers
-from .backend import BackendError, GenParams, add_usage, run_backends
+from .backend import BackendError, BackendStepper, GenParams, add_usage, run_backends
 from .members import Member, distinct_backends
 from .protocol import ConsensusResult
 
@@ -111,11 +111,11 @@ class MajorityVote:
             p = GenParams(**{**p.__dict__, "decision_targets": [" " + c for c in self.choices]})
         return p
 
-    def ask_many(self, questions: Sequence[str]) -> List[ConsensusResult]:
-        t0 = time.perf_counter()
-        handles = [[m.submit_prompt(self.prompt_fn(q), self._member_params(m)) for m in self.members]
-                   for q in questions]
-        _run_all(self.members)
+    def _submit(self, question: str) -> list:
+        return [m.submit_prompt(self.prompt_fn(question), self._member_params(m)) for m in self.members]
+
+    def _reduce(self, questions: Sequence[str], handles: Sequence[list], t0s: Sequence[float]) -> List[ConsensusResult]:
+        """Votes of finished member calls -> one result per question (one reducer launch for all)."""
         R, N = len(questions), len(self.members)
         votes = np.full((R, N), -1, dtype=np.int32)
         texts = [[""] * N for _ in range(R)]
@@ -135,10 +135,11 @@ class MajorityVote:
         with span("reduce", "strategy"):
             red = reducers.majority_vote_batch(votes, len(self.choices), self.tie_break, device=self.device,
                                                weights=weights)
-        dt = time.perf_counter() - t0
+        now = time.perf_counter()
         out = []
         for r, q in enumerate(questions):
             w = int(red.winner[r])
+            done = max((h.finished_at or 0.0) for h in handles[r]) if handles[r] else 0.0
             out.append(ConsensusResult(
                 question=q,
                 answer=self.choices[w] if w >= 0 else "",
@@ -146,7 +147,7 @@ class MajorityVote:
                 rounds=1,
                 member_calls=N,
                 unanimous=bool(red.unanimous[r]),
-                latency_s=max((h.finished_at or t0) for h in handles[r]) - t0 if handles[r] else dt,
+                latency_s=(done if done > t0s[r] else now) - t0s[r],
                 agreement=float(red.agreement[r]),
                 votes=[{"member": m.name, "class": int(votes[r, i]), "text": texts[r][i]}
                        for i, m in enumerate(self.members)],
@@ -154,8 +155,61 @@ class MajorityVote:
             ))
         return out
 
+    def ask_many(self, questions: Sequence[str]) -> List[ConsensusResult]:
+        t0 = time.perf_counter()
+        handles = [self._submit(q) for q in questions]
+        _run_all(self.members)
+        return self._reduce(questions, handles, [t0] * len(questions))
+
     def ask(self, question: str) -> ConsensusResult:
         return self.ask_many([question])[0]
+
+    def pool(self) -> "VotePool":
+        return VotePool(self)
+
+
+class VotePool:
+    """A single-phase strategy (MajorityVote) without batch boundaries: questions are admitted at
+    any time, the member engines are advanced one step at a time in between, and a question is
+    answered as soon as ITS member calls are done. Under a steady stream of arrivals every
+    engine then has prompts to prefill and chains to decode at the same time, which is the mix
+    the chip runs best (MFMA-bound and HBM-bound kernels in flight together), and the decode
+    batch stays full instead of draining at the end of every batch. Same interface as
+    protocol.SessionPool: submit -> ticket, pump -> [(ticket, result)], active, drain."""
+
+    def __init__(self, strategy: MajorityVote) -> None:
+        self.s = strategy
+        self.backends = distinct_backends(strategy.members)
+        self.stepper = BackendStepper(self.backends)
+        self.live: dict = {}          # ticket -> (question, handles, t0)
+        self._next = 0
+
+    @property
+    def active(self) -> int:
+        return len(self.live)
+
+    def submit(self, question: str) -> int:
+        t = self._next
+        self._next += 1
+        self.live[t] = (question, self.s._submit(question), time.perf_counter())
+        return t
+
+    def pump(self) -> List[tuple]:
+        done = [t for t, (_, hs, _) in self.live.items() if all(h.done for h in hs)]
+        finished: List[tuple] = []
+        if done:
+            rows = [self.live.pop(t) for t in done]
+            res = self.s._reduce([r[0] for r in rows], [r[1] for r in rows], [r[2] for r in rows])
+            finished = list(zip(done, res))
+        if self.live and not self.stepper.step() and not finished:
+            time.sleep(20e-6)
+        return finished
+
+    def drain(self) -> List[tuple]:
+        out = []
+        while self.live:
+            out += self.pump()
+        return out
 
 
 class SelfConsistency:

@@ -380,18 +380,20 @@ class Engine:
         # Decode steps are captured into hipGraphs by default. A step that contains collectives
         # (tensor / expert parallel members) is captured like any other when the group's
         # communicator is made of plain kernel launches (``capturable``: parallel/p2p.py).
-        # torch.distributed collectives are not captured: see the note in parallel/comm.py
-        # (TorchDistComm); such members run eagerly or from the cut modes below, and asking for
-        # graphs explicitly is an error rather than a way to end the process.
+        # torch.distributed collectives are captured only on request (use_graphs=True): they
+        # record and replay correctly under the thread-local capture mode used here, and end the
+        # process under the global mode (the process group's watchdog thread makes a HIP call
+        # while the capture is open; see TorchDistComm in parallel/comm.py). Any other
+        # communicator has no capture story and asking for graphs with it is an error.
         sharded = model.tp_size > 1 or model.ep_size > 1
         capturable = not sharded or bool(getattr(model.comm, "capturable", False))
         use_graphs_arg = use_graphs
         if use_graphs is None:
             use_graphs = capturable
         elif use_graphs and not capturable and self.device.type == "cuda" and \
-                os.environ.get("CONSENSUS_GRAPH_COLLECTIVES", "0") != "1":
-            raise ValueError(f"{name}: use_graphs=True needs a capturable group communicator (parallel.p2p.P2PComm); "
-                             f"{type(model.comm).__name__} issues library collectives that cannot be captured")
+                not getattr(model.comm, "capturable_thread_local", False):
+            raise ValueError(f"{name}: use_graphs=True needs a group communicator whose collectives can be recorded "
+                             f"into a hipGraph; {type(model.comm).__name__} declares none")
         self.use_graphs = bool(use_graphs) and self.device.type == "cuda"
         # Tensor-parallel members: graphs cut at the collectives (see capture_piecewise). Expert
         # parallel steps have data-dependent exchange sizes and stay eager.
@@ -850,49 +852,78 @@ class Engine:
         return s
 
 
+class EngineDriver:
+    """Steps several engines with their GPU work overlapped, one pass at a time, so a caller
+    can admit new requests between passes. Each engine's next step is enqueued on its own
+    stream as soon as its previous one has been collected, so up to len(engines) steps are in
+    flight. Decode steps of 7-8B models at small batch are dominated by short kernels whose
+    launch ramps and end-of-kernel cache write-backs leave CUs idle; kernels of the other
+    members fill those gaps.
+
+    Prefill steps are MFMA-bound, decode steps HBM-bound. With STAGGER_PREFILL only one engine
+    prefills at a time, so the others' decode steps run against a prefill instead of against
+    each other's prefills: the chip then has compute-bound and memory-bound kernels in flight
+    together. An engine whose next step is a prefill simply holds its plan until the slot frees."""
+
+    def __init__(self) -> None:
+        self.pending: dict = {}     # engine -> token of its step in flight
+        self.held: dict = {}        # engine -> prefill plan waiting for the prefill slot
+        self.prefilling = None      # the engine that owns the prefill slot
+
+    @property
+    def in_flight(self) -> int:
+        return len(self.pending) + len(self.held)
+
+    def advance(self, engines: Sequence["Engine"]) -> bool:
+        """One pass: collects the steps that have finished and launches each idle engine's next
+        one. Returns False when nothing could be collected or launched (every step in flight
+        is still running, or there is no work)."""
+        progressed = False
+        for e in engines:
+            tok = self.pending.get(e)
+            if tok is not None:
+                # Never block on one engine's long prefill while another's decode step is done.
+                if STAGGER_PREFILL and len(self.pending) > 1 and not e.step_done(tok):
+                    continue
+                del self.pending[e]
+                if self.prefilling is e:
+                    self.prefilling = None
+                e.end_step(tok)
+                progressed = True
+            plan = self.held.pop(e, None) or e.plan_step()
+            if plan is None:
+                continue
+            if STAGGER_PREFILL and plan.kind == PK.Prefill:
+                if self.prefilling is not None and self.prefilling is not e:
+                    self.held[e] = plan
+                    continue
+                self.prefilling = e
+            self.pending[e] = e.launch_step(plan)
+            progressed = True
+        if not progressed and not self.pending:
+            self.prefilling = None   # nothing in flight: never leave every engine waiting on a stale slot
+        return progressed
+
+    def reset(self) -> None:
+        """Forgets steps in flight (after a failure whose requests the caller has dropped)."""
+        self.pending.clear()
+        self.held.clear()
+        self.prefilling = None
+
+
 def run_engines(engines: Sequence["Engine"]) -> None:
-    """Drives several engines to completion with their steps overlapped: each engine's next
-    step is enqueued on its own stream as soon as its previous one has been collected, so up
-    to len(engines) steps are in flight. Decode steps of 7-8B models at small batch are
-    dominated by short kernels whose launch ramps and end-of-kernel cache write-backs leave
-    CUs idle; kernels of the other members fill those gaps."""
+    """Drives several engines to completion with their steps overlapped (EngineDriver)."""
     live = [e for e in engines if e.has_work()]
     if len(live) <= 1 or serialize_streams():
         for e in live:
             e.run_until_done()
         return
-    # Prefill steps are MFMA-bound, decode steps HBM-bound. With STAGGER_PREFILL only one engine
-    # prefills at a time, so the others' decode steps run against a prefill instead of against
-    # each other's prefills: the chip then has compute-bound and memory-bound kernels in flight
-    # together. An engine whose next step is a prefill simply holds its plan until the slot frees.
-    pending, held = {}, {}
-    prefilling = None          # the engine that owns the prefill slot
-    while live:
-        progressed = False
-        for e in list(live):
-            tok = pending.get(e)
-            if tok is not None:
-                # Never block on one engine's long prefill while another's decode step is done.
-                if STAGGER_PREFILL and len(pending) > 1 and not e.step_done(tok):
-                    continue
-                del pending[e]
-                e.end_step(tok)
-                progressed = True
-                if prefilling is e:
-                    prefilling = None
-            plan = held.pop(e, None) or e.plan_step()
-            if plan is None:
-                live.remove(e)
-                continue
-            if STAGGER_PREFILL and plan.kind == PK.Prefill:
-                if prefilling is not None and prefilling is not e:
-                    held[e] = plan
-                    continue
-                prefilling = e
-            pending[e] = e.launch_step(plan)
-            progressed = True
-        if not progressed:
-            if not pending:
-                prefilling = None   # nothing in flight: never leave every engine waiting on a stale slot
+    driver = EngineDriver()
+    while True:
+        if not driver.advance(live):
+            if not driver.in_flight:
+                live = [e for e in live if e.has_work()]
+                if not live:
+                    return
             else:
                 time.sleep(20e-6)

@@ -82,6 +82,23 @@ class SingleComm(Comm):
 
 
 class TorchDistComm(Comm):
+    """torch.distributed collectives (RCCL on GPUs, gloo on the host).
+
+    Recording these into a hipGraph: the process group runs a watchdog thread that queries the
+    events of outstanding work. While a stream capture in GLOBAL mode is open, a HIP call from
+    any thread is an error; the watchdog's query then throws inside its own thread
+    (ProcessGroupNCCL.cpp, the watchdog's run loop) and the process ends with SIGABRT. A capture
+    that is open for a few milliseconds usually slips between two polls; a decode step of a few
+    hundred launches does not. Captured in THREAD_LOCAL mode the same all-reduce records and
+    replays correctly: cold or warmed-up communicator, default group or sub-group
+    (benchmarks/micro/rccl_capture_probe.py runs every combination in a child process; only
+    "global mode, capture open for 2.5 s" aborts). The engine captures in thread-local mode,
+    so ``capturable_thread_local`` communicators may be captured when the caller asks for it;
+    the default for sharded members remains the peer-to-peer communicator (parallel/p2p.py),
+    whose collectives are single kernel launches."""
+
+    capturable_thread_local = True
+
     def __init__(self, dist, device: torch.device, group=None) -> None:
         self.dist, self.device, self.group = dist, device, group
         self.rank = dist.get_rank(group)

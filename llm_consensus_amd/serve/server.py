@@ -142,20 +142,17 @@ class ConsensusServer:
         return batch
 
     def _continuous_ok(self) -> bool:
-        """The reference protocol over backends that live in this process can be driven
-        without batch boundaries (SessionPool); everything else runs batch by batch."""
-        from ..consensus.protocol import Coordinator
-
+        """Strategies that offer a pool (the reference protocol, majority vote) over backends
+        that live in this process are driven without batch boundaries; everything else runs
+        batch by batch."""
         strat = getattr(self.ensemble, "strategy", None)
-        return (self.continuous and type(strat) is Coordinator
+        return (self.continuous and callable(getattr(strat, "pool", None))
                 and all(getattr(b, "incremental", False) for b in self.ensemble.backends.values()))
 
     def _drive_continuous(self) -> None:
         """New questions join the sessions in flight at the next engine step; every request is
         answered as soon as its own session (or generation) is done."""
-        from ..consensus.protocol import SessionPool
-
-        pool = SessionPool(self.ensemble.strategy)
+        pool = self.ensemble.strategy.pool()
         tickets: Dict[int, _Job] = {}
         direct: List[tuple] = []
         while not self._stop.is_set():
@@ -186,10 +183,13 @@ class ConsensusServer:
                     self._finish(j)
             try:
                 finished = pool.pump()
-                if not pool.active:          # nothing for the pool to step: direct requests only
-                    for be in {id(b): b for b in self.ensemble.backends.values()}.values():
-                        if be.engines():
-                            be.poll()
+                # The pool steps its members' backends while it has questions; everything else
+                # with queued direct requests (an embedder, or any backend when the pool is idle)
+                # is stepped here.
+                stepped = {id(b) for b in pool.backends} if pool.active else set()
+                for be in {id(b): b for b in self.ensemble.backends.values()}.values():
+                    if id(be) not in stepped and be.engines():
+                        be.poll()
             except Exception as e:  # noqa: BLE001  never let the driver die with waiters parked on it
                 log.error("engine step failed: %s", e)
                 for j in list(tickets.values()) + [j for _, j in direct]:
@@ -197,7 +197,7 @@ class ConsensusServer:
                     self._finish(j)
                 tickets.clear()
                 direct.clear()
-                pool = SessionPool(self.ensemble.strategy)
+                pool = self.ensemble.strategy.pool()
                 continue
             for t, res in finished:
                 j = tickets.pop(t)

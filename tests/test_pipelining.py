@@ -72,3 +72,35 @@ def test_pipelined_schedule_overlaps_phases_and_keeps_the_answers(strategy):
     window = [(t0, t1) for t0, t1, n in p_spans if n == "second"]
     lo, hi = window[0][0], window[-1][1]
     assert sum(1 for t0, _, n in p_spans if n in ("p0", "p1") and lo < t0 < hi) >= 2
+
+
+def vote_config() -> ConsensusConfig:
+    models = {f"m{i}": ModelSpec(name=f"m{i}", preset=p, seed=i + 1)
+              for i, p in enumerate(("tiny-llama", "tiny-qwen", "tiny-mistral"))}
+    members = [MemberConfig(name=n, model=n) for n in models]
+    return ConsensusConfig(strategy="majority_vote", decision_mode="logprob", models=models, members=members,
+                           sampling=SamplingConfig(temperature=0.0, max_new_tokens=6))
+
+
+def test_vote_pool_answers_match_batch_and_admits_while_running():
+    """Questions that arrive while others are being answered join the running engines; every
+    question gets the answer the batch form gives it."""
+    ens = build_ensemble(vote_config(), CPU)
+    batch = ens.ask_many(QUESTIONS)
+    pool = ens.strategy.pool()
+    tickets = {pool.submit(q): q for q in QUESTIONS[:2]}
+    got, late, pumps_before_late = {}, list(QUESTIONS[2:]), 0
+    while pool.active or late:
+        for t, res in pool.pump():
+            got[tickets[t]] = res
+        pumps_before_late += 1
+        if late and pumps_before_late >= 3:          # the first two are mid-generation by now
+            assert pool.active
+            q = late.pop(0)
+            tickets[pool.submit(q)] = q
+    assert [got[q].answer for q in QUESTIONS] == [r.answer for r in batch]
+    assert [[v["class"] for v in got[q].votes] for q in QUESTIONS] == [[v["class"] for v in r.votes] for r in batch]
+    assert all(got[q].latency_s > 0 for q in QUESTIONS)
+    for k in ("prompt_tokens", "completion_tokens"):          # the second pass hits the prefix cache
+        assert got[QUESTIONS[0]].usage[k] == batch[0].usage[k]
+    assert got[QUESTIONS[0]].usage["cached_tokens"] > 0
