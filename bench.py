@@ -87,6 +87,9 @@ def parse_args(argv=None):
     ap.add_argument("--prefill-tokens", type=int, default=8192, help="token budget of one prefill step")
     ap.add_argument("--no-graphs", action="store_true")
     ap.add_argument("--out", default=None, help="also write the JSON line to this file")
+    ap.add_argument("--section-timeout", type=float, default=480.0,
+                    help="multi-GPU runs: seconds a sharded workload (D, E) may take before it is abandoned")
+    ap.add_argument("--in-child", action="store_true", help=argparse.SUPPRESS)
     a = ap.parse_args(argv)
     wl = ALL_WORKLOADS if a.workload.lower() == "all" else "".join(w.strip().upper() for w in a.workload.split(","))
     if not wl or any(w not in ALL_WORKLOADS for w in wl):
@@ -458,6 +461,77 @@ def run_configured(ctx: Ctx, cfg, per_replica: int, prompt_len: int, steps: int,
     return sec
 
 
+# ------------------------------------------------------------------------------------ isolation
+def _child_args(argv, letter: str, out_path: str):
+    """The rank's own command line with the workload and output replaced."""
+    keep, skip = [], False
+    for tok in argv:
+        if skip:
+            skip = False
+            continue
+        if tok in ("--workload", "--out"):
+            skip = True
+            continue
+        if tok.startswith("--workload=") or tok.startswith("--out=") or tok == "--in-child":
+            continue
+        keep.append(tok)
+    return keep + ["--workload", letter, "--out", out_path, "--in-child"]
+
+
+def run_isolated(ctx: Ctx, a, argv, letter: str):
+    """Multi-GPU runs: a sharded workload (D: tensor-parallel judge, E: expert-parallel MoE) runs
+    in child processes, one per rank, with a process group of their own and a time limit. Its
+    collectives go through peer-to-peer kernels over IPC-mapped memory; should that path fail or
+    stall on a machine (it then times out and flags an error instead of hanging), the section
+    is tried once more on RCCL collectives, and if that fails too the section reports the error.
+    Either way the replica workloads measured before it keep their numbers and the line is
+    printed. Children are new interpreters started as child processes; nothing is replaced."""
+    import signal
+    import tempfile
+
+    lead = ctx.rank == 0
+    errors = []
+    attempts = [("p2p kernels over IPC-mapped memory", {}), ("rccl", {"LC_P2P": "0"})]
+    if getattr(ctx, "p2p_failed", False):
+        attempts = attempts[1:]                    # an earlier section already found that path unusable here
+    for label, extra in attempts:
+        port, path = ctx.comm.broadcast_object(
+            (_free_port(), os.path.join(tempfile.gettempdir(), f"bench_{letter}_{os.getpid()}_{len(errors)}.json"))
+            if lead else None, 0)
+        env = {k: v for k, v in os.environ.items() if not k.startswith("TORCHELASTIC_")}
+        env.update(MASTER_PORT=str(port), MASTER_ADDR="127.0.0.1", **extra)
+        log_path = path + f".rank{ctx.rank}.log"
+        with open(log_path, "w") as log:
+            p = subprocess.Popen([sys.executable, str(Path(__file__).resolve())] + _child_args(argv, letter, path),
+                                 env=env, stdout=subprocess.DEVNULL, stderr=log, start_new_session=True)
+            try:
+                rc = p.wait(a.section_timeout)
+            except subprocess.TimeoutExpired:
+                os.killpg(p.pid, signal.SIGKILL)       # the child's own process group, nothing else
+                p.wait()
+                rc = "timeout"
+        if ctx.comm.all_true(rc == 0):
+            sec = None
+            if lead:
+                full = json.loads(Path(path).read_text())
+                key = {"D": "judge_consensus", "E": "moe_medoid"}[letter]
+                sec = full[key]
+                sec["collectives"] = label
+                if errors:
+                    sec["first_attempt"] = errors
+            return ctx.comm.broadcast_object(sec, 0)
+        tail = ""
+        try:
+            tail = Path(log_path).read_text()[-400:]
+        except OSError:
+            pass
+        mine = f"{label}: rank {ctx.rank} exit {rc}" + (f" ({tail.strip().splitlines()[-1]})" if tail.strip() else "")
+        errors.append([e for e in ctx.comm.all_gather_object(mine if rc != 0 else None) if e][:4])
+        if not extra:
+            ctx.p2p_failed = True
+    return {"error": errors}
+
+
 # ------------------------------------------------------------------------------------ main
 def main(argv=None) -> int:
     argv = sys.argv[1:] if argv is None else argv
@@ -512,24 +586,32 @@ def main(argv=None) -> int:
     if out["value"] is not None:
         out["vs_baseline"] = round(out["value"] / REFERENCE_BOUND_ANSWERS_PER_S, 1)
     aux_warm = min(a.warmup, 1)
+    isolate = ctx.world > 1 and not a.in_child
     if "D" in wl:
-        cfg = W.judge_config(ctx.world, a.judge_questions, a.prompt_len, a.new_tokens, samp, a.proposer_model,
-                             a.judge_model, bs=ctx.bs, prefill_tokens=a.prefill_tokens)
-        out["judge_consensus"] = run_configured(
-            ctx, cfg, a.judge_questions, a.prompt_len, a.aux_steps, aux_warm,
-            f"consensus answers/sec, 4x {a.proposer_model} proposers + {a.judge_model} judge (log-prob scoring)",
-            judge_tp=cfg.models["judge"].tp, proposers=4)
+        if isolate:
+            out["judge_consensus"] = run_isolated(ctx, a, argv, "D")
+        else:
+            cfg = W.judge_config(ctx.world, a.judge_questions, a.prompt_len, a.new_tokens, samp, a.proposer_model,
+                                 a.judge_model, bs=ctx.bs, prefill_tokens=a.prefill_tokens)
+            out["judge_consensus"] = run_configured(
+                ctx, cfg, a.judge_questions, a.prompt_len, a.aux_steps, aux_warm,
+                f"consensus answers/sec, 4x {a.proposer_model} proposers + {a.judge_model} judge (log-prob scoring)",
+                judge_tp=cfg.models["judge"].tp, proposers=4)
     if "E" in wl:
-        cfg = W.moe_medoid_config(ctx.world, a.moe_questions, a.prompt_len, a.new_tokens, samp, a.moe_samples,
-                                  a.moe_model, a.embed_model, a.moe_experts, ctx.bs, a.prefill_tokens)
-        out["moe_medoid"] = run_configured(
-            ctx, cfg, a.moe_questions, a.prompt_len, a.aux_steps, aux_warm,
-            f"consensus answers/sec, {a.moe_model} proposer x{a.moe_samples} samples + {a.embed_model} embedding medoid",
-            expert_parallel=cfg.models["moe"].ep, ep_mode=cfg.models["moe"].ep_mode, samples_per_question=a.moe_samples)
+        if isolate:
+            out["moe_medoid"] = run_isolated(ctx, a, argv, "E")
+        else:
+            cfg = W.moe_medoid_config(ctx.world, a.moe_questions, a.prompt_len, a.new_tokens, samp, a.moe_samples,
+                                      a.moe_model, a.embed_model, a.moe_experts, ctx.bs, a.prefill_tokens)
+            out["moe_medoid"] = run_configured(
+                ctx, cfg, a.moe_questions, a.prompt_len, a.aux_steps, aux_warm,
+                f"consensus answers/sec, {a.moe_model} proposer x{a.moe_samples} samples + {a.embed_model} embedding medoid",
+                expert_parallel=cfg.models["moe"].ep, ep_mode=cfg.models["moe"].ep_mode,
+                samples_per_question=a.moe_samples)
     if "A" not in wl:
         # no headline run requested: promote the first measured section so the line stays well formed
         for key in ("self_consistency", "reference_protocol", "judge_consensus", "moe_medoid"):
-            if key in out:
+            if key in out and "value" in out[key]:
                 out.update({"metric": out[key]["metric"], "value": out[key]["value"],
                             "ms_per_step": out[key]["ms_per_step"], "steps": out[key]["steps"]})
                 out["vs_baseline"] = round(out["value"] / REFERENCE_BOUND_ANSWERS_PER_S, 1)

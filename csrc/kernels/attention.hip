@@ -391,7 +391,7 @@ __global__ __launch_bounds__(64 * NW) void attn_decode_mw_kernel(
     const int32_t* __restrict__ block_tables, int max_blocks, const int32_t* __restrict__ ctx_lens,
     const int32_t* __restrict__ kv_begin, bf16_t* __restrict__ out, float* __restrict__ part_o,
     float* __restrict__ part_lse, int np_total, int Hq, int Hkv, int lbs, float scale2, int window) {
-  __shared__ float sm_o[NW][8][DH];
+  __shared__ float sm_o[NW][8][DH + 8];   // +8: the 8 rows x 2 lane halves written at once hit disjoint banks
   __shared__ float sm_m[NW][8], sm_l[NW][8];
   const int kvh = blockIdx.x, b = blockIdx.y, split = blockIdx.z, nsplit = gridDim.z;
   const int lane = threadIdx.x & 63;

@@ -77,3 +77,22 @@ def test_mismatches_are_errors_not_silent_single_device_runs():
         assert q.returncode == 2 and "visible" in q.stderr and not q.stdout.strip()
     r = run_bench(["--gpus", "2", "--workload", "A", "--placement", "spread"] + TINY)
     assert r.returncode != 0 and "spread" in r.stderr
+
+
+def test_sharded_sections_run_isolated_and_a_failing_one_does_not_take_the_line_down():
+    """At more than one rank D and E run in child processes with their own process group. The
+    first test above passes through that path; here the children get no time at all, both
+    attempts (peer-to-peer kernels, then RCCL) are abandoned, and the line still carries A."""
+    p = run_bench(["--gpus", "2", "--workload", "A,D", "--section-timeout", "0.05"] + TINY)
+    assert p.returncode == 0, p.stderr[-3000:]
+    out = json_line(p)
+    assert out["value"] > 0 and out["n_gpus"] == 2
+    err = out["judge_consensus"]["error"]
+    assert len(err) == 2 and "timeout" in json.dumps(err)
+
+
+def test_isolated_section_reports_which_collectives_it_used():
+    p = run_bench(["--gpus", "2", "--workload", "E"] + TINY)
+    assert p.returncode == 0, p.stderr[-3000:]
+    out = json_line(p)
+    assert out["moe_medoid"]["collectives"].startswith("p2p") and out["value"] == out["moe_medoid"]["value"]
