@@ -168,8 +168,9 @@ def make_strategy(cfg: ConsensusConfig, members: List[Member], device):
         return SelfConsistency(voters[0], cfg.k_chains, cfg.choices, cfg.tie_break_enum(), cfg.decision_mode,
                                device=dev)
     if cfg.strategy == "judge_logprob":
-        return JudgeLogprob(voters, judges or voters[-1:], device=dev, micro_batches=cfg.micro_batches)
+        return JudgeLogprob(voters, judges or voters[-1:], device=dev, micro_batches=cfg.micro_batches,
+                            min_micro_batch=cfg.min_micro_batch)
     if cfg.strategy == "embedding_medoid":
         return EmbeddingMedoid(voters, (embedders or voters)[0], samples_per_member=cfg.samples_per_member, device=dev,
-                               micro_batches=cfg.micro_batches)
+                               micro_batches=cfg.micro_batches, min_micro_batch=cfg.min_micro_batch)
     raise ValueError(cfg.strategy)

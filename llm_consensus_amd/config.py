@@ -87,6 +87,7 @@ class ConsensusConfig:
     samples_per_member: int = 1       # embedding_medoid: candidates sampled per proposer and question
     micro_batches: int = 2            # judge_logprob / embedding_medoid: parts of a question batch pipelined
     #                                   through the two phases (1 = propose everything, then judge everything)
+    min_micro_batch: int = 32         # ... and the fewest questions such a part may hold
     choices: str = "ABCD"
     tie_break: str = "lowest_class"
     deadline_s: Optional[float] = None

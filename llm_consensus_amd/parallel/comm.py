@@ -97,10 +97,10 @@ class TorchDistComm(Comm):
     the default for sharded members remains the peer-to-peer communicator (parallel/p2p.py),
     whose collectives are single kernel launches."""
 
-    capturable_thread_local = True
-
     def __init__(self, dist, device: torch.device, group=None) -> None:
         self.dist, self.device, self.group = dist, device, group
+        # only RCCL enqueues its collectives on the stream; gloo stages through the host
+        self.capturable_thread_local = str(dist.get_backend(group)).lower() == "nccl"
         self.rank = dist.get_rank(group)
         self.world = dist.get_world_size(group)
 

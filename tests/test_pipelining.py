@@ -23,6 +23,7 @@ def two_phase_config(strategy: str, micro_batches: int) -> ConsensusConfig:
     members = [MemberConfig(name="p0", model="p0"), MemberConfig(name="p1", model="p1"),
                MemberConfig(name="second", model="second", role=role)]
     return ConsensusConfig(strategy=strategy, models=models, members=members, micro_batches=micro_batches,
+                           min_micro_batch=1,
                            sampling=SamplingConfig(temperature=0.0, max_new_tokens=6))
 
 
@@ -72,6 +73,19 @@ def test_pipelined_schedule_overlaps_phases_and_keeps_the_answers(strategy):
     window = [(t0, t1) for t0, t1, n in p_spans if n == "second"]
     lo, hi = window[0][0], window[-1][1]
     assert sum(1 for t0, _, n in p_spans if n in ("p0", "p1") and lo < t0 < hi) >= 2
+
+
+def test_small_batches_are_not_cut():
+    from llm_consensus_amd.consensus.strategies import MIN_MICRO_BATCH, _two_stage_pipeline
+
+    seen = []
+    _two_stage_pipeline(MIN_MICRO_BATCH + 5, 4, lambda rng: seen.append(("p", len(rng))), [],
+                        lambda rng: seen.append(("j", len(rng))), [])
+    assert seen == [("p", MIN_MICRO_BATCH + 5), ("j", MIN_MICRO_BATCH + 5)]
+    seen.clear()
+    _two_stage_pipeline(4 * MIN_MICRO_BATCH, 2, lambda rng: seen.append(("p", len(rng))), [],
+                        lambda rng: seen.append(("j", len(rng))), [])
+    assert [s for s in seen if s[0] == "p"] == [("p", 2 * MIN_MICRO_BATCH)] * 2
 
 
 def vote_config() -> ConsensusConfig:
