@@ -86,6 +86,8 @@ def parse_args(argv=None):
     ap.add_argument("--top-p", type=float, default=0.95)
     ap.add_argument("--prefill-tokens", type=int, default=8192, help="token budget of one prefill step")
     ap.add_argument("--no-graphs", action="store_true")
+    ap.add_argument("--no-mix-decode", action="store_true",
+                    help="A, B, C: prefill-only and decode-only steps (decoding chains do not ride along in prefill steps)")
     ap.add_argument("--out", default=None, help="also write the JSON line to this file")
     ap.add_argument("--section-timeout", type=float, default=480.0,
                     help="multi-GPU runs: seconds a sharded workload (D, E) may take before it is abandoned")
@@ -262,7 +264,7 @@ def run_replica_workloads(ctx: Ctx, out: dict) -> None:
         model = TransformerModel.random_init(cfg, dev, seed=1234 + i)
         eng = Engine(model, num_kv_blocks=(max_seqs + 8) * blocks_per_seq + 64, block_size=bs,
                      max_batch_seqs=max(256, max_seqs), max_prefill_tokens=a.prefill_tokens,
-                     max_model_len=seq_len + 64, use_graphs=not a.no_graphs, name=name)
+                     max_model_len=seq_len + 64, use_graphs=not a.no_graphs, name=name, mix_decode=not a.no_mix_decode)
         be = EngineBackend(eng, ByteLevelTokenizer(cfg.vocab_size), stop_at_eos=False)
         gp = GenParams(temperature=a.temperature, top_p=a.top_p, max_new_tokens=a.new_tokens, seed=17 * i)
         members.append(Member(personas[i % len(personas)], be, params=gp))
