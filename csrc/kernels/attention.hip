@@ -200,7 +200,7 @@ LC_DEVICE void finish_and_store(AttnState<DH>& st, bf16_t* out_bf16, float* out_
 }
 
 // ------------------------------------------------------------------ prefill
-// grid (q_tile, kv_head x ceil(G/4), seq); a workgroup is 4 waves = up to 4 of the G query heads
+// one workgroup per (pair of q tiles, kv_head x ceil(G/4), seq); a workgroup is 4 waves = up to 4 of the G query heads
 // that share a kv head, 32 query rows each (256 threads leave each wave the ~180 VGPRs a
 // Dh = 128 tile needs). The 32-key K/V tiles are staged ONCE per workgroup in LDS by LDS-DMA
 // and every wave reads its MFMA fragments from there, instead of each wave pulling the same
@@ -212,7 +212,7 @@ LC_DEVICE void finish_and_store(AttnState<DH>& st, bf16_t* out_bf16, float* out_
 // keys). A DMA writes lane-linear, so the bank swizzle is applied to the SOURCE chunk a lane
 // fetches: K position (key, c) holds chunk c ^ (key & (CH-1)) of that key, V position (d, c)
 // holds chunk c ^ ((d >> 2) & 3) of row d. Fragment reads apply the same XOR.
-constexpr int PF_NSTAGE = 3;
+constexpr int PF_NSTAGE = 4;
 
 template <int DH>
 struct PrefillLds {
@@ -230,54 +230,84 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_lds_kernel(
     const bf16_t* __restrict__ Q, int q_stride, const bf16_t* __restrict__ Kc, const bf16_t* __restrict__ Vt,
     const int32_t* __restrict__ block_tables, int max_blocks, const int32_t* __restrict__ cu_q,
     const int32_t* __restrict__ ctx_lens, bf16_t* __restrict__ out, int Hq, int Hkv, int lbs, float scale2,
-    int window) {
+    int window, int gx, int gy) {
   using L = PrefillLds<DH>;
   constexpr int PPW = L::PIECES / 4;   // DMA instructions per wave per tile
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int G = Hq / Hkv, nsub = (G + 3) / 4;
-  const int s = blockIdx.z, kvh = blockIdx.y / nsub, sub = blockIdx.y % nsub, tile = blockIdx.x;
+  // Consecutive workgroup ids go round-robin over the 8 XCDs, each with its own L2. The launch is
+  // one-dimensional and the id is re-read so that the workgroups that share a (sequence, kv head),
+  // i.e. the same K/V tiles, are consecutive on ONE XCD: logical = (id % 8) * (n / 8) + id / 8.
+  int logical = blockIdx.x;
+  {
+    const int n = gridDim.x, full = n & ~7;
+    if (logical < full) logical = (logical & 7) * (full >> 3) + (logical >> 3);
+  }
+  const int bx = logical % gx, by = (logical / gx) % gy, s = logical / (gx * gy);
+  const int kvh = by / nsub, sub = by % nsub;
   const int q0 = cu_q[s], q_len = cu_q[s + 1] - q0;
-  if (tile * 32 >= q_len) return;
+  // A workgroup takes the query tiles bx and nq-1-bx of its sequence, the long one first: under
+  // the causal mask tile j attends j+1 key tiles, so every pair costs the same and the fixed
+  // cost of a workgroup (block table, first tiles in flight) is paid once per nq+1 key tiles.
+  const int nq = (q_len + 31) >> 5;
+  const int t_heavy = nq - 1 - bx;
+  if (t_heavy < bx) return;
   const int lane = threadIdx.x & 63;
   const int g = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const bool has_head = sub * 4 + g < G;   // a wave without a head still moves its share of K/V
   const int head = kvh * G + min(sub * 4 + g, G - 1);
   const int ctx = ctx_lens[s];
   const int base_pos = ctx - q_len;
-  const int i = tile * 32 + (lane & 31);
-  const bool valid = has_head && i < q_len;
-  const int pos = base_pos + i;
-  const int hi_q = valid ? pos + 1 : 0;
-  const int lo_q = (valid && window > 0 && pos + 1 > window) ? pos + 1 - window : 0;
   const int BS = 1 << lbs;
   const int32_t* bt = block_tables + static_cast<size_t>(s) * max_blocks;
   const size_t kblk_stride = static_cast<size_t>(Hkv) * BS * DH;
-
-  bf16x8 qf[DH / 16];
-  load_q<DH>(qf, valid ? Q + static_cast<size_t>(q0 + i) * q_stride + head * DH : nullptr, lane);
-  AttnState<DH> st;
-  init_state<DH>(st);
-
-  const int last_row = min(tile * 32 + 31, q_len - 1);
-  const int kv_hi = base_pos + last_row + 1;
-  int kv_lo = 0;
-  if (window > 0) {
-    const int first_pos = base_pos + tile * 32;
-    kv_lo = first_pos + 1 > window ? first_pos + 1 - window : 0;
-  }
-  const int t_lo = kv_lo >> 5, nt = ((kv_hi + 31) >> 5) - t_lo;   // 32-key tiles [t_lo, t_lo + nt)
+  const int r = lane & 31, h = lane >> 5;
+  const int pi_r = (r & ~0xC) | ((r & 4) << 1) | ((r & 8) >> 1);
 
   // The block-table entries this workgroup needs go to LDS first. Looking them up in global
   // memory while tiles are in flight would make every DMA address wait on vmcnt(0) -- i.e.
   // drain the ring once per piece; LDS reads are counted separately (lgkmcnt).
   int32_t* bt_s = reinterpret_cast<int32_t*>(smem + PF_NSTAGE * L::STAGE);
-  for (int b = threadIdx.x; b <= ((kv_hi - 1) >> lbs); b += 256) bt_s[b] = bt[b];
+  {
+    const int kv_top = base_pos + min(t_heavy * 32 + 31, q_len - 1) + 1;
+    for (int b = threadIdx.x; b <= ((kv_top - 1) >> lbs); b += 256) bt_s[b] = bt[b];
+  }
   __syncthreads();
 
-  auto issue_tile = [&](int t) {
-    if (t >= nt) return;
-    char* stage = smem + (t % PF_NSTAGE) * L::STAGE;
-    const int k0 = (t_lo + t) << 5;
+  // Per query tile of the pair (0 = the long one): rows, visibility bounds, key-tile range.
+  const bool two = t_heavy != bx;
+  int row_i[2], hi_qs[2], lo_qs[2], kv_his[2], t_los[2], nts[2];
+  bool valids[2];
+  bf16x8 qf[2][DH / 16];
+#pragma unroll
+  for (int p = 0; p < 2; ++p) {
+    const int tile = p == 0 ? t_heavy : bx;
+    row_i[p] = tile * 32 + r;
+    valids[p] = has_head && row_i[p] < q_len && (p == 0 || two);
+    const int pos = base_pos + row_i[p];
+    hi_qs[p] = valids[p] ? pos + 1 : 0;
+    lo_qs[p] = (valids[p] && window > 0 && pos + 1 > window) ? pos + 1 - window : 0;
+    kv_his[p] = base_pos + min(tile * 32 + 31, q_len - 1) + 1;
+    int kv_lo = 0;
+    if (window > 0) {
+      const int first_pos = base_pos + tile * 32;
+      kv_lo = first_pos + 1 > window ? first_pos + 1 - window : 0;
+    }
+    t_los[p] = kv_lo >> 5;
+    nts[p] = (p == 0 || two) ? ((kv_his[p] + 31) >> 5) - t_los[p] : 0;   // 32-key tiles [t_lo, t_lo + nt)
+    // both tiles' query rows are fetched up front: nothing but LDS-DMA is issued once the ring runs
+    load_q<DH>(qf[p], valids[p] ? Q + static_cast<size_t>(q0 + row_i[p]) * q_stride + head * DH : nullptr, lane);
+  }
+  const int nt0 = nts[0], total = nts[0] + nts[1];
+
+  // The ring runs through both query tiles without draining: virtual tile v < nt0 belongs to
+  // the long query tile, the rest to the short one.
+  auto issue_tile = [&](int v) {
+    if (v >= total) return;
+    const int p = v >= nt0 ? 1 : 0;
+    const int kv_hi = p ? kv_his[1] : kv_his[0];
+    const int k0 = ((p ? t_los[1] : t_los[0]) + (p ? v - nt0 : v)) << 5;
+    char* stage = smem + (v % PF_NSTAGE) * L::STAGE;
 #pragma unroll
     for (int q = 0; q < PPW; ++q) {
       const int piece = q * 4 + g;
@@ -300,38 +330,47 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_lds_kernel(
       }
     }
   };
-  auto wait_in_flight = [&](int tiles) {   // at most one tile stays in flight
-    if (tiles == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW) : "memory");
+  auto wait_in_flight = [&](int tiles) {   // at most `tiles` younger tiles stay in flight
+    if (tiles <= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if (tiles == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW) : "memory");
+    else if (tiles == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PPW) : "memory");
+    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * PPW) : "memory");
+  };
+  static_assert(PF_NSTAGE >= 3 && PF_NSTAGE <= 5, "wait_in_flight covers up to three younger tiles");
+
+  auto run_tiles = [&](const bf16x8 (&q)[DH / 16], int v0, int n, int t_lo, int lo_q, int hi_q, bool valid,
+                       int row) {
+    AttnState<DH> st;
+    init_state<DH>(st);
+    for (int v = v0; v < v0 + n; ++v) {
+      wait_in_flight(min(PF_NSTAGE - 2, total - 1 - v));
+      asm volatile("" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      issue_tile(v + PF_NSTAGE - 1);
+      const char* stage = smem + (v % PF_NSTAGE) * L::STAGE;
+      const int k0 = (t_lo + v - v0) << 5;
+      bf16x8 kf[DH / 16], vf[DH / 32][2];
+#pragma unroll
+      for (int kk = 0; kk < DH / 16; ++kk)
+        kf[kk] = *reinterpret_cast<const bf16x8*>(stage + pi_r * (DH * 2) + (((2 * kk + h) ^ (pi_r & (L::CH - 1))) << 4));
+#pragma unroll
+      for (int sx = 0; sx < 2; ++sx)
+#pragma unroll
+        for (int b = 0; b < DH / 32; ++b) {
+          const int d = b * 32 + r;
+          vf[b][sx] = *reinterpret_cast<const bf16x8*>(stage + L::K_BYTES + d * 64 + (((2 * sx + h) ^ ((d >> 2) & 3)) << 4));
+        }
+      process_tile<DH>(st, q, kf, vf, k0, lo_q, hi_q, scale2, lane);
+    }
+    bf16_t* orow = valid ? out + static_cast<size_t>(q0 + row) * (Hq * DH) + head * DH : nullptr;
+    finish_and_store<DH>(st, orow, nullptr, nullptr, lane);
   };
 
-  const int r = lane & 31, h = lane >> 5;
-  const int pi_r = (r & ~0xC) | ((r & 4) << 1) | ((r & 8) >> 1);
-  issue_tile(0);
-  issue_tile(1);
-  for (int t = 0; t < nt; ++t) {
-    wait_in_flight(t + 1 < nt ? 1 : 0);
-    asm volatile("" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    issue_tile(t + 2);
-    const char* stage = smem + (t % PF_NSTAGE) * L::STAGE;
-    const int k0 = (t_lo + t) << 5;
-    bf16x8 kf[DH / 16], vf[DH / 32][2];
 #pragma unroll
-    for (int kk = 0; kk < DH / 16; ++kk)
-      kf[kk] = *reinterpret_cast<const bf16x8*>(stage + pi_r * (DH * 2) + (((2 * kk + h) ^ (pi_r & (L::CH - 1))) << 4));
-#pragma unroll
-    for (int sx = 0; sx < 2; ++sx)
-#pragma unroll
-      for (int b = 0; b < DH / 32; ++b) {
-        const int d = b * 32 + r;
-        vf[b][sx] = *reinterpret_cast<const bf16x8*>(stage + L::K_BYTES + d * 64 + (((2 * sx + h) ^ ((d >> 2) & 3)) << 4));
-      }
-    process_tile<DH>(st, qf, kf, vf, k0, lo_q, hi_q, scale2, lane);
-  }
-  bf16_t* orow = valid ? out + static_cast<size_t>(q0 + i) * (Hq * DH) + head * DH : nullptr;
-  finish_and_store<DH>(st, orow, nullptr, nullptr, lane);
+  for (int v = 0; v < PF_NSTAGE - 1; ++v) issue_tile(v);
+  run_tiles(qf[0], 0, nt0, t_los[0], lo_qs[0], hi_qs[0], valids[0], row_i[0]);
+  if (two) run_tiles(qf[1], nt0, nts[1], t_los[1], lo_qs[1], hi_qs[1], valids[1], row_i[1]);
 }
 
 // ------------------------------------------------------------------ decode
@@ -626,13 +665,14 @@ LC_EXPORT int lc_attn_prefill(const void* Q, int q_stride, const void* Kc, const
   if (n_seqs <= 0 || max_q_len <= 0) return 0;
   if (Hq % Hkv || (Dh != 64 && Dh != 128) || block_size % 8 || (block_size & (block_size - 1))) return -1;
   const int G = Hq / Hkv;
-  const dim3 grid((max_q_len + 31) / 32, Hkv * ((G + 3) / 4), n_seqs), block(256);
+  const int gx = ((max_q_len + 31) / 32 + 1) / 2, gy = Hkv * ((G + 3) / 4);
+  const dim3 grid(static_cast<unsigned>(gx) * gy * n_seqs), block(256);
   const float scale2 = scale * 1.4426950408889634f;
   const int lbs = ilog2(block_size);
 #define LC_ARGS                                                                                          \
   static_cast<const bf16_t*>(Q), q_stride, static_cast<const bf16_t*>(Kc), static_cast<const bf16_t*>(Vt), \
       static_cast<const int32_t*>(block_tables), max_blocks, static_cast<const int32_t*>(cu_q),          \
-      static_cast<const int32_t*>(ctx_lens), static_cast<bf16_t*>(out), Hq, Hkv, lbs, scale2, window
+      static_cast<const int32_t*>(ctx_lens), static_cast<bf16_t*>(out), Hq, Hkv, lbs, scale2, window, gx, gy
   if (max_blocks > 8192) return -1;   // the block-table slice kept in LDS
   const size_t bt_bytes = static_cast<size_t>(max_blocks) * sizeof(int32_t);
   if (Dh == 128)
