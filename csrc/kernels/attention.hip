@@ -34,6 +34,19 @@ struct TileCtx {
   float scale2;                    // softmax scale * log2(e)
 };
 
+// Consecutive workgroup ids go round-robin over the 8 XCDs, each with its own L2. Workgroups
+// come in groups of `gx` that read the same K/V tiles; this returns the logical index
+// (group * gx + member) for a physical id such that the members of a group are all on one XCD
+// while consecutive GROUPS still go round-robin over the XCDs. Spreading by groups matters: the
+// work per group is uneven (ragged prompts, empty group slots), and a mapping that hands each XCD
+// a contiguous run of groups would put a whole long sequence on one eighth of the chip.
+LC_DEVICE int xcd_group_remap(int id, int gx, int n_groups) {
+  const int full = (n_groups & ~7) * gx;
+  if (id >= full) return id;
+  const int x = id & 7, k = id >> 3;
+  return (x + 8 * (k / gx)) * gx + k % gx;
+}
+
 template <int DH>
 struct AttnState {
   f32x16 o[DH / 32];  // O^T blocks: row d = blk*32 + (reg&3) + 8*(reg>>2) + 4*h, col q = lane&31
@@ -235,14 +248,9 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_lds_kernel(
   constexpr int PPW = L::PIECES / 4;   // DMA instructions per wave per tile
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int G = Hq / Hkv, nsub = (G + 3) / 4;
-  // Consecutive workgroup ids go round-robin over the 8 XCDs, each with its own L2. The launch is
-  // one-dimensional and the id is re-read so that the workgroups that share a (sequence, kv head),
-  // i.e. the same K/V tiles, are consecutive on ONE XCD: logical = (id % 8) * (n / 8) + id / 8.
-  int logical = blockIdx.x;
-  {
-    const int n = gridDim.x, full = n & ~7;
-    if (logical < full) logical = (logical & 7) * (full >> 3) + (logical >> 3);
-  }
+  // One-dimensional launch: the workgroups of one (sequence, kv head) share K/V tiles and are
+  // placed on one XCD.
+  const int logical = xcd_group_remap(blockIdx.x, gx, gridDim.x / gx);
   const int bx = logical % gx, by = (logical / gx) % gy, s = logical / (gx * gy);
   const int kvh = by / nsub, sub = by % nsub;
   const int q0 = cu_q[s], q_len = cu_q[s + 1] - q0;
@@ -558,16 +566,16 @@ __global__ __launch_bounds__(64 * NW) void attn_prefix_mw_kernel(
   float(*sm_o)[32][DH] = reinterpret_cast<float(*)[32][DH]>(pm_smem);
   float(*sm_m)[32] = reinterpret_cast<float(*)[32]>(pm_smem + sizeof(float) * NW * 32 * DH);
   float(*sm_l)[32] = sm_m + NW;
+  const int bx = blockIdx.x, kvh = blockIdx.y;
   const int grp = blockIdx.z / nsplit, split = blockIdx.z % nsplit;
-  const int kvh = blockIdx.y;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int G = Hq / Hkv;
   const int first = group_first[grp], count = group_count[grp];
   const int plen = group_shared_blocks[grp] << lbs;
-  if (blockIdx.x * 32 >= count * G) return;     // block-uniform: an empty group slot
+  if (bx * 32 >= count * G) return;     // block-uniform: an empty group slot
   const int q = lane & 31, hh = lane >> 5;
-  const int row = blockIdx.x * 32 + q;
+  const int row = bx * 32 + q;
   const bool valid = row < count * G;
   const int b = first + row / G;
   const int head = kvh * G + row % G;
@@ -597,7 +605,7 @@ __global__ __launch_bounds__(64 * NW) void attn_prefix_mw_kernel(
   __syncthreads();
   for (int e = threadIdx.x; e < 32 * DH; e += 64 * NW) {
     const int qq = e / DH, d = e % DH;
-    const int r2 = blockIdx.x * 32 + qq;
+    const int r2 = bx * 32 + qq;
     if (r2 >= count * G) continue;
     float mx = kNegBig;
 #pragma unroll
