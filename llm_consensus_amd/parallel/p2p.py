@@ -63,7 +63,11 @@ def _L():
 # Messages (bytes per rank) above which the all-reduce runs as reduce-scatter + all-gather.
 TWO_SHOT_BYTES = int(os.environ.get("LC_P2P_TWO_SHOT_BYTES", str(1 << 20)))
 DEFAULT_STAGE_BYTES = int(os.environ.get("LC_P2P_STAGE_BYTES", str(64 << 20)))
-TIMEOUT_S = float(os.environ.get("LC_P2P_TIMEOUT_S", "20"))
+# How long a collective waits for a peer before it flags the group as failed. Ranks of a group
+# reach the same step at different times (a rank that also hosts another member may be in that
+# member's prefill, the first use of a batch shape records a graph): generous, because the only
+# cost of a long limit is how late a dead peer is noticed.
+TIMEOUT_S = float(os.environ.get("LC_P2P_TIMEOUT_S", "60"))
 # Most blocks one collective launches (0 = the kernel library's default of 64). Lower it when
 # several ranks share one GPU (tests): waiting blocks hold CU slots.
 GRID_CAP = int(os.environ.get("LC_P2P_GRID_CAP", "0"))
