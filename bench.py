@@ -74,10 +74,10 @@ def parse_args(argv=None):
     ap.add_argument("--aux-steps", type=int, default=None, help="timed steps of C, D, E (default: min(steps, 6))")
     ap.add_argument("--proto-questions", type=int, default=8, help="questions per GPU per step (workload C)")
     ap.add_argument("--proto-prompt-len", type=int, default=128)
-    ap.add_argument("--judge-questions", type=int, default=16, help="questions per replica per step (workload D)")
+    ap.add_argument("--judge-questions", type=int, default=16, help="questions per GPU per step (workload D)")
     ap.add_argument("--judge-model", default="llama-3-70b")
     ap.add_argument("--proposer-model", default="llama-3-8b")
-    ap.add_argument("--moe-questions", type=int, default=16, help="questions per replica per step (workload E)")
+    ap.add_argument("--moe-questions", type=int, default=16, help="questions per GPU per step (workload E)")
     ap.add_argument("--moe-model", default="mixtral-8x7b")
     ap.add_argument("--moe-experts", type=int, default=8, help="experts of --moe-model (bounds the EP degree)")
     ap.add_argument("--embed-model", default="qwen2.5-0.5b")
@@ -593,20 +593,25 @@ def main(argv=None) -> int:
         if isolate:
             out["judge_consensus"] = run_isolated(ctx, a, argv, "D")
         else:
-            cfg = W.judge_config(ctx.world, a.judge_questions, a.prompt_len, a.new_tokens, samp, a.proposer_model,
+            # D and E use all GPUs for ONE ensemble (the judge's TP group next to the proposers, the
+            # MoE's experts over every GPU), so their batch grows with the GPU count: --judge-questions
+            # and --moe-questions are per GPU.
+            nq = a.judge_questions * ctx.world
+            cfg = W.judge_config(ctx.world, nq, a.prompt_len, a.new_tokens, samp, a.proposer_model,
                                  a.judge_model, bs=ctx.bs, prefill_tokens=a.prefill_tokens)
             out["judge_consensus"] = run_configured(
-                ctx, cfg, a.judge_questions, a.prompt_len, a.aux_steps, aux_warm,
+                ctx, cfg, nq, a.prompt_len, a.aux_steps, aux_warm,
                 f"consensus answers/sec, 4x {a.proposer_model} proposers + {a.judge_model} judge (log-prob scoring)",
                 judge_tp=cfg.models["judge"].tp, proposers=4)
     if "E" in wl:
         if isolate:
             out["moe_medoid"] = run_isolated(ctx, a, argv, "E")
         else:
-            cfg = W.moe_medoid_config(ctx.world, a.moe_questions, a.prompt_len, a.new_tokens, samp, a.moe_samples,
+            nq = a.moe_questions * ctx.world
+            cfg = W.moe_medoid_config(ctx.world, nq, a.prompt_len, a.new_tokens, samp, a.moe_samples,
                                       a.moe_model, a.embed_model, a.moe_experts, ctx.bs, a.prefill_tokens)
             out["moe_medoid"] = run_configured(
-                ctx, cfg, a.moe_questions, a.prompt_len, a.aux_steps, aux_warm,
+                ctx, cfg, nq, a.prompt_len, a.aux_steps, aux_warm,
                 f"consensus answers/sec, {a.moe_model} proposer x{a.moe_samples} samples + {a.embed_model} embedding medoid",
                 expert_parallel=cfg.models["moe"].ep, ep_mode=cfg.models["moe"].ep_mode,
                 samples_per_question=a.moe_samples)
