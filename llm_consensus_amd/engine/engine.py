@@ -340,6 +340,50 @@ class _DecodeGraph:
                 coll()
 
 
+class _StepStaging:
+    """Host arrays of one prefill step, packed into ONE pinned buffer and shipped with ONE
+    asynchronous copy (the decode path has its own fixed-layout arena, _DecodeGraph). ``put``
+    returns a ticket; after ``ship`` the ticket's device view is ``view(ticket)``. The engine has
+    one step in flight and waits for it before planning the next, so both buffers are free
+    again when the next step packs."""
+
+    _TORCH = {np.dtype(np.int32): torch.int32, np.dtype(np.int64): torch.int64, np.dtype(np.float32): torch.float32}
+
+    def __init__(self, device: torch.device) -> None:
+        self.device = device
+        self.cap = 0
+        self.host = self.dev = None
+        self.items: List[tuple] = []
+        self.used = 0
+
+    def begin(self) -> None:
+        self.items, self.used = [], 0
+
+    def put(self, a: np.ndarray) -> int:
+        a = np.ascontiguousarray(a)
+        if a.dtype not in self._TORCH:
+            raise TypeError(f"unsupported staging dtype {a.dtype}")
+        off = (self.used + 15) & ~15
+        self.items.append((off, a))
+        self.used = off + a.nbytes
+        return len(self.items) - 1
+
+    def ship(self) -> None:
+        need = max(self.used, 16)
+        if need > self.cap:
+            self.cap = max(need * 2, 1 << 16)
+            self.host = torch.empty(self.cap, dtype=torch.uint8, pin_memory=self.device.type == "cuda")
+            self.dev = torch.empty(self.cap, dtype=torch.uint8, device=self.device)
+        hv = self.host.numpy()
+        for off, a in self.items:
+            hv[off:off + a.nbytes] = a.reshape(-1).view(np.uint8)
+        self.dev[:need].copy_(self.host[:need], non_blocking=True)
+
+    def view(self, ticket: int) -> torch.Tensor:
+        off, a = self.items[ticket]
+        return self.dev[off:off + a.nbytes].view(self._TORCH[a.dtype]).view(a.shape)
+
+
 class Engine:
     def __init__(self, model: TransformerModel, num_kv_blocks: Optional[int] = None, block_size: int = 64,
                  max_batch_seqs: int = 256, max_prefill_tokens: int = 8192, max_model_len: int = 4096,
@@ -414,6 +458,7 @@ class Engine:
         # on the default stream, one engine at a time, and results must not change.
         own_stream = self.device.type == "cuda" and not serialize_streams()
         self.stream = torch.cuda.Stream(device=self.device) if own_stream else None
+        self._staging = _StepStaging(self.device)
         if self.stream is not None:
             self.stream.wait_stream(torch.cuda.current_stream(self.device))   # weights were written there
         self._graphs: Dict[tuple, _DecodeGraph] = {}
@@ -547,44 +592,32 @@ class Engine:
 
     def _prefill_launch(self, plan):
         m = self.model
-        tok = self._dev(plan.token_ids)
         rf = plan.rider_first
         n_seq = len(plan.seq_ids)
         n_riders = n_seq - rf if rf >= 0 else 0
         cu = plan.cu_q
-        if n_riders:
-            # Mixed step: sequences [rf, n_seq) are decoding chains with one token each.
-            bt, ctx = self._dev(plan.block_tables), self._dev(plan.context_lens)
-            riders = AttnMeta(is_prefill=False, block_tables=bt[rf:], ctx_lens=ctx[rf:],
-                              nsplit=ops.choose_kv_splits(n_riders, m.hkv, int(plan.context_lens[rf:].max()))
-                              if self.device.type == "cuda" else 1)
-            meta = AttnMeta(is_prefill=True, block_tables=bt[:rf], ctx_lens=ctx[:rf], cu_q=self._dev(cu[:rf + 1]),
-                            max_q_len=int(np.diff(cu[:rf + 1]).max()), riders=riders, prefill_tokens=int(cu[rf]))
-            self.metrics.inc("prefill.rider_tokens", n_riders)
-        else:
-            meta = AttnMeta(is_prefill=True, block_tables=self._dev(plan.block_tables),
-                            ctx_lens=self._dev(plan.context_lens), cu_q=self._dev(cu), max_q_len=int(np.diff(cu).max()))
-        hidden = m.forward(tok, self._dev(plan.positions), self._dev(plan.slot_mapping), meta, self.kv)
         req_ids = plan.request_ids
+        n_last = len(plan.last_rows)
+        # ---- everything the step reads from the host goes into one staging buffer ----
+        sg = self._staging
+        sg.begin()
+        t_tok, t_pos, t_slot = sg.put(plan.token_ids), sg.put(plan.positions), sg.put(plan.slot_mapping)
+        t_bt, t_ctx = sg.put(plan.block_tables), sg.put(plan.context_lens)
+        t_cu = sg.put(cu[:rf + 1] if n_riders else cu)
         # Embed requests: one pooling launch over the chunks of all of them in this step (fp32
         # sums of the final hidden states per chunk); a prompt cut into several chunks adds its
         # chunk sums up, the mean and the L2 normalisation happen when the request finishes.
         emb = [i for i, rid in enumerate(req_ids[:n_seq - n_riders])
                if self._reqs[int(rid)].kind == core.RequestKind.Embed]
         if emb:
-            sums = ops.embed_pool_ranges(hidden, self._dev(np.array([cu[i] for i in emb], dtype=np.int32)),
-                                         self._dev(np.array([cu[i + 1] for i in emb], dtype=np.int32)), mode=2)
-            for j, i in enumerate(emb):
-                st = self._reqs[int(req_ids[i])]
-                st.embed_sum = sums[j] if st.embed_sum is None else st.embed_sum + sums[j]
-                st.embed_count += int(cu[i + 1] - cu[i])
-        toks = lps = logits = None
-        n_last = len(plan.last_rows)
+            t_eb = sg.put(np.array([cu[i] for i in emb], dtype=np.int32))
+            t_ee = sg.put(np.array([cu[i + 1] for i in emb], dtype=np.int32))
+        t_need = t_samp = None
+        slots = []
         if n_last or n_riders:
             # logits rows: the prompts that end in this step, then the riders (the step's last rows)
             need = np.concatenate([plan.last_rows, cu[rf:n_seq]]) if n_riders else plan.last_rows
-            rows = hidden[self._dev(need, torch.int64)]
-            logits = m.logits(rows)
+            t_need = sg.put(np.asarray(need).astype(np.int64))
             slots = self.sched.prefill_sample_layout(plan)
             if slots or n_riders:
                 ri = [s.last_row_index for s in slots] + list(range(n_last, n_last + n_riders))
@@ -601,14 +634,35 @@ class Engine:
                         temp.append(e[0]); top_p.append(e[1]); top_k.append(e[2])
                     seeds += [int(x) for x in plan.seeds]
                     steps += [int(x) for x in plan.step_index]
-                toks, lps = ops.sample(
-                    logits,
-                    self._dev(np.array(temp, dtype=np.float32), torch.float32),
-                    self._dev(np.array(top_p, dtype=np.float32), torch.float32),
-                    self._dev(np.array(top_k, dtype=np.int32)),
-                    self._dev(np.array(seeds, dtype=np.uint64).astype(np.int64), torch.int64),
-                    self._dev(np.array(steps, dtype=np.int32)),
-                    self._dev(np.array(ri, dtype=np.int32)))
+                t_samp = (sg.put(np.array(temp, dtype=np.float32)), sg.put(np.array(top_p, dtype=np.float32)),
+                          sg.put(np.array(top_k, dtype=np.int32)),
+                          sg.put(np.array(seeds, dtype=np.uint64).astype(np.int64)),
+                          sg.put(np.array(steps, dtype=np.int32)), sg.put(np.array(ri, dtype=np.int32)))
+        sg.ship()
+        bt, ctx = sg.view(t_bt), sg.view(t_ctx)
+        if n_riders:
+            # Mixed step: sequences [rf, n_seq) are decoding chains with one token each.
+            riders = AttnMeta(is_prefill=False, block_tables=bt[rf:], ctx_lens=ctx[rf:],
+                              nsplit=ops.choose_kv_splits(n_riders, m.hkv, int(plan.context_lens[rf:].max()))
+                              if self.device.type == "cuda" else 1)
+            meta = AttnMeta(is_prefill=True, block_tables=bt[:rf], ctx_lens=ctx[:rf], cu_q=sg.view(t_cu),
+                            max_q_len=int(np.diff(cu[:rf + 1]).max()), riders=riders, prefill_tokens=int(cu[rf]))
+            self.metrics.inc("prefill.rider_tokens", n_riders)
+        else:
+            meta = AttnMeta(is_prefill=True, block_tables=bt, ctx_lens=ctx, cu_q=sg.view(t_cu),
+                            max_q_len=int(np.diff(cu).max()))
+        hidden = m.forward(sg.view(t_tok), sg.view(t_pos), sg.view(t_slot), meta, self.kv)
+        if emb:
+            sums = ops.embed_pool_ranges(hidden, sg.view(t_eb), sg.view(t_ee), mode=2)
+            for j, i in enumerate(emb):
+                st = self._reqs[int(req_ids[i])]
+                st.embed_sum = sums[j] if st.embed_sum is None else st.embed_sum + sums[j]
+                st.embed_count += int(cu[i + 1] - cu[i])
+        toks = lps = logits = None
+        if t_need is not None:
+            logits = m.logits(hidden[sg.view(t_need)])
+            if t_samp is not None:
+                toks, lps = ops.sample(logits, *(sg.view(t) for t in t_samp))
         return toks, lps, logits
 
     def _prefill_finish(self, plan, state) -> None:
