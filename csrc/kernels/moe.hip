@@ -10,108 +10,142 @@ namespace {
 constexpr int kMaxExperts = 16;
 constexpr int kMaxTopK = 4;
 
-// One wave per token: logits[e] = x . Wr[e], softmax over experts, top-k, renormalise.
-__global__ void moe_router_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ Wr, int T,
-                                  int d, int E, int topk, int32_t* __restrict__ topk_ids,
-                                  float* __restrict__ topk_w, float* __restrict__ router_logits) {
-  const int t = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-  const int lane = threadIdx.x & 63;
-  if (t >= T) return;
+// Softmax over the experts' logits, top-k, renormalise; run by one thread per token. `logit`
+// may live in LDS or registers; loops have compile-time bounds so nothing is indexed dynamically
+// in registers (that would go through scratch memory).
+LC_DEVICE void route_token(const float* logit, int E, int topk, int32_t* __restrict__ ids_out,
+                           float* __restrict__ w_out, float* __restrict__ logits_out) {
+  float lg[kMaxExperts];
+  float mx = -INFINITY;
+#pragma unroll
+  for (int e = 0; e < kMaxExperts; ++e) {
+    // HF Mixtral rounds router logits to the activation dtype before the softmax.
+    lg[e] = e < E ? bf16_to_f32(f32_to_bf16(logit[e])) : -INFINITY;
+    if (e < E && logits_out) logits_out[e] = lg[e];
+    mx = fmaxf(mx, lg[e]);
+  }
+  float p[kMaxExperts], sum = 0.f;
+#pragma unroll
+  for (int e = 0; e < kMaxExperts; ++e) {
+    p[e] = e < E ? __expf(lg[e] - mx) : -1.f;      // -1: never chosen
+    sum += e < E ? p[e] : 0.f;
+  }
+  float w[kMaxTopK], wsum = 0.f;
+  int ids[kMaxTopK];
+  unsigned used = 0;
+#pragma unroll
+  for (int k = 0; k < kMaxTopK; ++k) {
+    if (k < topk) {
+      int best = 0;
+      float bp = -2.f;
+#pragma unroll
+      for (int e = 0; e < kMaxExperts; ++e) {
+        const bool free_e = !((used >> e) & 1u);
+        if (free_e && p[e] > bp) {       // strict: the lowest index wins a tie
+          bp = p[e];
+          best = e;
+        }
+      }
+      used |= 1u << best;
+      ids[k] = best;
+      w[k] = bp / sum;
+      wsum += w[k];
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < kMaxTopK; ++k) {
+    if (k < topk) {
+      ids_out[k] = ids[k];
+      w_out[k] = w[k] / wsum;
+    }
+  }
+}
+
+// logits[e] = x . Wr[e]. WAVES waves share a token: decode steps have a few dozen tokens, and
+// with one wave per token the whole router is 16 workgroups walking 8 dependent rounds of loads
+// (42 us at 64 tokens). Four waves per token issue all of a token's loads at once.
+template <int WAVES>
+__global__ __launch_bounds__(256) void moe_router_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ Wr,
+                                                         int T, int d, int E, int topk,
+                                                         int32_t* __restrict__ topk_ids, float* __restrict__ topk_w,
+                                                         float* __restrict__ router_logits) {
+  constexpr int TPB = 4 / WAVES;                      // tokens per 256-thread block
+  __shared__ float part[4][kMaxExperts];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int t = blockIdx.x * TPB + wave / WAVES;
+  const int sub = wave % WAVES;                       // this wave's share of the row
   float acc[kMaxExperts];
 #pragma unroll
   for (int e = 0; e < kMaxExperts; ++e) acc[e] = 0.f;
-  const bf16_t* xr = x + static_cast<size_t>(t) * d;
-  for (int c = lane; c < d / 8; c += 64) {
-    const bf16x8 xv = *reinterpret_cast<const bf16x8*>(xr + c * 8);
-    float xf[8];
+  if (t < T) {
+    const bf16_t* xr = x + static_cast<size_t>(t) * d;
+    for (int c = sub * 64 + lane; c < d / 8; c += 64 * WAVES) {
+      const bf16x8 xv = *reinterpret_cast<const bf16x8*>(xr + c * 8);
+      float xf[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) xf[j] = bf16_to_f32(static_cast<bf16_t>(xv[j]));
+      for (int j = 0; j < 8; ++j) xf[j] = bf16_to_f32(static_cast<bf16_t>(xv[j]));
 #pragma unroll
-    for (int e = 0; e < kMaxExperts; ++e) {
-      if (e < E) {
-        const bf16x8 wv = *reinterpret_cast<const bf16x8*>(Wr + static_cast<size_t>(e) * d + c * 8);
+      for (int e = 0; e < kMaxExperts; ++e) {
+        if (e < E) {
+          const bf16x8 wv = *reinterpret_cast<const bf16x8*>(Wr + static_cast<size_t>(e) * d + c * 8);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) acc[e] += xf[j] * bf16_to_f32(static_cast<bf16_t>(wv[j]));
+          for (int j = 0; j < 8; ++j) acc[e] += xf[j] * bf16_to_f32(static_cast<bf16_t>(wv[j]));
+        }
       }
     }
   }
 #pragma unroll
-  for (int e = 0; e < kMaxExperts; ++e) acc[e] = wave_sum(acc[e]);
+  for (int e = 0; e < kMaxExperts; ++e)
+    if (e < E) acc[e] = wave_sum(acc[e]);
   if (lane == 0) {
-    // HF Mixtral rounds router logits to the activation dtype before the softmax.
-    float mx = -INFINITY;
-    for (int e = 0; e < E; ++e) {
-      acc[e] = bf16_to_f32(f32_to_bf16(acc[e]));
-      if (router_logits) router_logits[static_cast<size_t>(t) * E + e] = acc[e];
-      mx = fmaxf(mx, acc[e]);
+#pragma unroll
+    for (int e = 0; e < kMaxExperts; ++e) part[wave][e] = acc[e];
+  }
+  __syncthreads();
+  if (lane == 0 && sub == 0 && t < T) {
+    float logit[kMaxExperts];
+#pragma unroll
+    for (int e = 0; e < kMaxExperts; ++e) {
+      float v = 0.f;
+#pragma unroll
+      for (int q = 0; q < WAVES; ++q) v += part[wave + q][e];
+      logit[e] = v;
     }
-    float p[kMaxExperts], sum = 0.f;
-    for (int e = 0; e < E; ++e) {
-      p[e] = __expf(acc[e] - mx);
-      sum += p[e];
-    }
-    int ids[kMaxTopK];
-    float w[kMaxTopK], wsum = 0.f;
-    for (int k = 0; k < topk; ++k) {
-      int best = -1;
-      for (int e = 0; e < E; ++e) {
-        bool used = false;
-        for (int j = 0; j < k; ++j) used |= ids[j] == e;
-        if (!used && (best < 0 || p[e] > p[best])) best = e;
-      }
-      ids[k] = best;
-      w[k] = p[best] / sum;
-      wsum += w[k];
-    }
-    for (int k = 0; k < topk; ++k) {
-      topk_ids[static_cast<size_t>(t) * topk + k] = ids[k];
-      topk_w[static_cast<size_t>(t) * topk + k] = w[k] / wsum;
-    }
+    route_token(logit, E, topk, topk_ids + static_cast<size_t>(t) * topk, topk_w + static_cast<size_t>(t) * topk,
+                router_logits ? router_logits + static_cast<size_t>(t) * E : nullptr);
   }
 }
 
 // Single block. Builds offsets[E+1] (rows per expert, prefix-summed), sorted_src[slot] =
 // source token row, and slot_of[t*topk+k] = slot, for A = T*topk assignments.
+// Deterministic placement: assignment a goes after all assignments a' < a of the same expert.
+// Each thread owns a contiguous chunk of assignments; its per-expert counts are prefix-scanned
+// over the block (wave scan + per-wave totals), which also yields the per-expert totals, so the
+// ids are read from memory once and the block synchronises once.
 __global__ __launch_bounds__(1024) void moe_permute_kernel(const int32_t* __restrict__ topk_ids, int A,
                                                            int topk, int E, int32_t* __restrict__ offsets,
                                                            int32_t* __restrict__ sorted_src,
                                                            int32_t* __restrict__ slot_of) {
-  __shared__ int counts[kMaxExperts];
-  __shared__ int base[kMaxExperts + 1];
-  __shared__ int cursor[kMaxExperts];
-  if (threadIdx.x < kMaxExperts) {
-    counts[threadIdx.x] = 0;
-    cursor[threadIdx.x] = 0;
-  }
-  __syncthreads();
-  for (int a = threadIdx.x; a < A; a += blockDim.x) atomicAdd(&counts[topk_ids[a]], 1);
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    int run = 0;
-    for (int e = 0; e < E; ++e) {
-      base[e] = run;
-      offsets[e] = run;
-      run += counts[e];
-    }
-    base[E] = run;
-    offsets[E] = run;
-  }
-  __syncthreads();
-  // Deterministic placement: assignment a goes after all assignments a' < a of the same
-  // expert. Each thread handles a contiguous chunk; chunk-level counts are exchanged by a
-  // serial pass per expert (E <= 16, chunks = blockDim.x).
-  __shared__ int chunk_cnt[kMaxExperts][1024 / 64];  // per-wave counts to keep LDS small
+  __shared__ int chunk_cnt[kMaxExperts][1024 / 64];   // inclusive per-wave totals
+  constexpr int kKeep = 4;                            // ids kept in registers per thread
   const int per = (A + blockDim.x - 1) / blockDim.x;
   const int a0 = threadIdx.x * per, a1 = min(A, a0 + per);
+  int kept[kKeep];
   int mine[kMaxExperts];
 #pragma unroll
   for (int e = 0; e < kMaxExperts; ++e) mine[e] = 0;
-  for (int a = a0; a < a1; ++a) {
+#pragma unroll
+  for (int i = 0; i < kKeep; ++i) kept[i] = (i < per && a0 + i < a1) ? topk_ids[a0 + i] : -1;
+#pragma unroll
+  for (int i = 0; i < kKeep; ++i) {
+#pragma unroll
+    for (int q = 0; q < kMaxExperts; ++q) mine[q] += (q == kept[i]) ? 1 : 0;
+  }
+  for (int a = a0 + kKeep; a < a1; ++a) {
     const int e = topk_ids[a];
 #pragma unroll
     for (int q = 0; q < kMaxExperts; ++q) mine[q] += (q == e) ? 1 : 0;
   }
-  // exclusive prefix over threads for every expert: wave scan + cross-wave offsets
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
   int excl[kMaxExperts];
 #pragma unroll
@@ -126,39 +160,64 @@ __global__ __launch_bounds__(1024) void moe_permute_kernel(const int32_t* __rest
     if (lane == 63) chunk_cnt[e][wid] = incl;
   }
   __syncthreads();
+  // excl[e] becomes this thread's first slot for expert e: expert base + rows of earlier waves +
+  // rows of earlier lanes
+  int run = 0;
 #pragma unroll
   for (int e = 0; e < kMaxExperts; ++e) {
-    int before = 0;
-    for (int w = 0; w < wid && w < nw; ++w) before += chunk_cnt[e][w];
-    excl[e] += before;
+    int before = 0, total = 0;
+    for (int w = 0; w < nw; ++w) {
+      const int c = chunk_cnt[e][w];
+      before += w < wid ? c : 0;
+      total += c;
+    }
+    excl[e] += run + before;
+    if (threadIdx.x == 0 && e < E) offsets[e] = run;
+    run += e < E ? total : 0;
   }
-  for (int a = a0; a < a1; ++a) {
-    const int e = topk_ids[a];
-    int pos = 0;
+  if (threadIdx.x == 0) offsets[E] = run;
+  auto place = [&](int a, int e) {
+    int slot = 0;
 #pragma unroll
     for (int q = 0; q < kMaxExperts; ++q)
-      if (q == e) pos = excl[q]++;
-    const int slot = base[e] + pos;
+      if (q == e) slot = excl[q]++;
     sorted_src[slot] = a / topk;
     slot_of[a] = slot;
-  }
+  };
+#pragma unroll
+  for (int i = 0; i < kKeep; ++i)
+    if (kept[i] >= 0) place(a0 + i, kept[i]);
+  for (int a = a0 + kKeep; a < a1; ++a) place(a, topk_ids[a]);
 }
 
-// out[t,:] = sum_k w[t,k] * Y[slot_of[t*topk+k], :]   (fp32 accumulate, bf16 store)
-__global__ void moe_combine_kernel(const bf16_t* __restrict__ Y, const int32_t* __restrict__ slot_of,
-                                   const float* __restrict__ topk_w, bf16_t* __restrict__ out, int T, int d,
-                                   int topk) {
-  const int t = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-  const int lane = threadIdx.x & 63;
+// out[t,:] = sum_k w[t,k] * Y[slot_of[t*topk+k], :]   (fp32 accumulate, bf16 store). WAVES waves
+// share a token row (decode steps: few tokens, all of a row's loads in flight at once).
+template <int WAVES>
+__global__ __launch_bounds__(256) void moe_combine_kernel(const bf16_t* __restrict__ Y,
+                                                          const int32_t* __restrict__ slot_of,
+                                                          const float* __restrict__ topk_w, bf16_t* __restrict__ out,
+                                                          int T, int d, int topk) {
+  constexpr int TPB = 4 / WAVES;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int t = blockIdx.x * TPB + wave / WAVES;
+  const int sub = wave % WAVES;
   if (t >= T) return;
-  for (int c = lane; c < d / 8; c += 64) {
-    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    for (int k = 0; k < topk; ++k) {
-      const int slot = slot_of[static_cast<size_t>(t) * topk + k];
-      const float w = topk_w[static_cast<size_t>(t) * topk + k];
-      const bf16x8 v = *reinterpret_cast<const bf16x8*>(Y + static_cast<size_t>(slot) * d + c * 8);
+  int slots[kMaxTopK];
+  float ws[kMaxTopK];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) acc[j] += w * bf16_to_f32(static_cast<bf16_t>(v[j]));
+  for (int k = 0; k < kMaxTopK; ++k) {
+    slots[k] = k < topk ? slot_of[static_cast<size_t>(t) * topk + k] : 0;
+    ws[k] = k < topk ? topk_w[static_cast<size_t>(t) * topk + k] : 0.f;
+  }
+  for (int c = sub * 64 + lane; c < d / 8; c += 64 * WAVES) {
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < kMaxTopK; ++k) {
+      if (k < topk) {
+        const bf16x8 v = *reinterpret_cast<const bf16x8*>(Y + static_cast<size_t>(slots[k]) * d + c * 8);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] += ws[k] * bf16_to_f32(static_cast<bf16_t>(v[j]));
+      }
     }
     bf16x8 o;
 #pragma unroll
@@ -298,9 +357,12 @@ LC_EXPORT int lc_moe_router(const void* x, const void* Wr, int T, int d, int E, 
                             void* topk_w, void* router_logits, hipStream_t stream) {
   if (T <= 0) return 0;
   if (E > kMaxExperts || topk > kMaxTopK || topk > E || d % 8) return -1;
-  moe_router_kernel<<<dim3((T + 3) / 4), dim3(256), 0, stream>>>(
-      static_cast<const bf16_t*>(x), static_cast<const bf16_t*>(Wr), T, d, E, topk,
-      static_cast<int32_t*>(topk_ids), static_cast<float*>(topk_w), static_cast<float*>(router_logits));
+#define LC_ARGS                                                                             \
+  static_cast<const bf16_t*>(x), static_cast<const bf16_t*>(Wr), T, d, E, topk,             \
+      static_cast<int32_t*>(topk_ids), static_cast<float*>(topk_w), static_cast<float*>(router_logits)
+  if (T <= 1024) moe_router_kernel<4><<<dim3(T), dim3(256), 0, stream>>>(LC_ARGS);
+  else moe_router_kernel<1><<<dim3((T + 3) / 4), dim3(256), 0, stream>>>(LC_ARGS);
+#undef LC_ARGS
   LC_RETURN_LAST_ERROR();
 }
 
@@ -308,7 +370,9 @@ LC_EXPORT int lc_moe_permute(const void* topk_ids, int T, int topk, int E, void*
                              void* slot_of, hipStream_t stream) {
   if (T <= 0) return 0;
   if (E > kMaxExperts) return -1;
-  moe_permute_kernel<<<dim3(1), dim3(1024), 0, stream>>>(static_cast<const int32_t*>(topk_ids), T * topk, topk,
+  // small steps: fewer waves to scan and to synchronise
+  const int threads = T * topk <= 256 ? 256 : 1024;
+  moe_permute_kernel<<<dim3(1), dim3(threads), 0, stream>>>(static_cast<const int32_t*>(topk_ids), T * topk, topk,
                                                          E, static_cast<int32_t*>(offsets),
                                                          static_cast<int32_t*>(sorted_src),
                                                          static_cast<int32_t*>(slot_of));
@@ -319,8 +383,12 @@ LC_EXPORT int lc_moe_combine(const void* Y, const void* slot_of, const void* top
                              int topk, hipStream_t stream) {
   if (T <= 0) return 0;
   if (d % 8) return -1;
-  moe_combine_kernel<<<dim3((T + 3) / 4), dim3(256), 0, stream>>>(
-      static_cast<const bf16_t*>(Y), static_cast<const int32_t*>(slot_of), static_cast<const float*>(topk_w),
-      static_cast<bf16_t*>(out), T, d, topk);
+  if (topk > kMaxTopK) return -1;
+#define LC_ARGS                                                                                             \
+  static_cast<const bf16_t*>(Y), static_cast<const int32_t*>(slot_of), static_cast<const float*>(topk_w),   \
+      static_cast<bf16_t*>(out), T, d, topk
+  if (T <= 1024) moe_combine_kernel<4><<<dim3(T), dim3(256), 0, stream>>>(LC_ARGS);
+  else moe_combine_kernel<1><<<dim3((T + 3) / 4), dim3(256), 0, stream>>>(LC_ARGS);
+#undef LC_ARGS
   LC_RETURN_LAST_ERROR();
 }
