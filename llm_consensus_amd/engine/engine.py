@@ -28,6 +28,7 @@ log = get_logger("consensus.engine")
 PK = core.StepPlan.Kind
 # One member engine prefills at a time while the others decode (see run_engines).
 STAGGER_PREFILL = os.environ.get("CONSENSUS_STAGGER_PREFILL", "1") == "1"
+PREFIX_MIN_GROUP_ROWS = int(os.environ.get("CONSENSUS_PREFIX_MIN_GROUP_ROWS", "6"))
 
 
 def serialize_streams() -> bool:
@@ -726,8 +727,13 @@ class Engine:
         B = len(plan.seq_ids)
         gshared = plan.group_shared_blocks
         gcount = plan.group_count
+        # The shared-prefix pass pays when a group is large: it reads the prompt's KV once per
+        # group instead of once per chain, but adds a second attention launch and the merge.
+        # With 4 chains per prompt (64 rows, 512-token prompts) the plain pass takes 32 us per
+        # layer against 43 us for prefix + suffix + merge; with 16 chains it is 56 us against
+        # more than 100. The switch is the size of the step's largest group.
         with_prefix = bool(len(gshared)) and bool(((gshared > 0) & (gcount > 1)).any()) and \
-            int(gcount.max()) <= self.max_group_rows
+            PREFIX_MIN_GROUP_ROWS <= int(gcount.max()) <= self.max_group_rows
         bucket = self._bucket(B) if (self.use_graphs or self.piecewise) else B
         max_ctx = int(plan.context_lens.max())
         ctx_class = next((c for c in self.ctx_classes if c >= max_ctx), self.ctx_classes[-1])
