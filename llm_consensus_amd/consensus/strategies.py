@@ -178,7 +178,7 @@ class MajorityVote:
 
 
 class VotePool:
-    """A single-phase strategy (MajorityVote) without batch boundaries: questions are admitted at
+    """A single-phase strategy (MajorityVote, SelfConsistency) without batch boundaries: questions are admitted at
     any time, the member engines are advanced one step at a time in between, and a question is
     answered as soon as ITS member calls are done. Under a steady stream of arrivals every
     engine then has prompts to prefill and chains to decode at the same time, which is the mix
@@ -186,7 +186,7 @@ class VotePool:
     batch stays full instead of draining at the end of every batch. Same interface as
     protocol.SessionPool: submit -> ticket, pump -> [(ticket, result)], active, drain."""
 
-    def __init__(self, strategy: MajorityVote) -> None:
+    def __init__(self, strategy) -> None:
         self.s = strategy
         self.backends = distinct_backends(strategy.members)
         self.stepper = BackendStepper(self.backends)
@@ -200,7 +200,8 @@ class VotePool:
     def submit(self, question: str) -> int:
         t = self._next
         self._next += 1
-        self.live[t] = (question, self.s._submit(question), time.perf_counter())
+        handles = self.s._submit(question, t) if isinstance(self.s, SelfConsistency) else self.s._submit(question)
+        self.live[t] = (question, handles, time.perf_counter())
         return t
 
     def pump(self) -> List[tuple]:
@@ -239,16 +240,15 @@ class SelfConsistency:
         self.numeric = numeric
         self.device = device
 
-    def ask_many(self, questions: Sequence[str]) -> List[ConsensusResult]:
-        t0 = time.perf_counter()
+    def _submit(self, question: str, qi: int) -> list:
+        """One request of K forked chains; ``qi`` offsets the seed so questions draw different chains."""
         base = self.params or self.member.params
-        handles = []
-        for qi, q in enumerate(questions):
-            p = GenParams(**{**base.__dict__, "n": self.k, "seed": base.seed + 1000003 * qi})
-            if self.decision_mode == "logprob" and not self.numeric:
-                p.decision_targets = [" " + c for c in self.choices]
-            handles.append(self.member.submit_prompt(self.prompt_fn(q), p))
-        _run_all([self.member])
+        p = GenParams(**{**base.__dict__, "n": self.k, "seed": base.seed + 1000003 * qi})
+        if self.decision_mode == "logprob" and not self.numeric:
+            p.decision_targets = [" " + c for c in self.choices]
+        return [self.member.submit_prompt(self.prompt_fn(question), p)]
+
+    def _reduce(self, questions: Sequence[str], handles: Sequence[list], t0s: Sequence[float]) -> List[ConsensusResult]:
         R = len(questions)
         votes = np.full((R, self.k), -1, dtype=np.int32)
         labels: List[List[str]] = [[] for _ in range(R)]  # class id -> answer string (free-form mode)
@@ -256,7 +256,7 @@ class SelfConsistency:
         cached = [0] * R
         for r in range(R):
             try:
-                res = handles[r].result()
+                res = handles[r][0].result()
             except BackendError as e:
                 log.error("%s failed: %s", self.member.name, e)
                 continue
@@ -277,6 +277,7 @@ class SelfConsistency:
         ncls = max(len(self.choices), max((len(l) for l in labels), default=0), 1)
         with span("reduce", "strategy"):
             red = reducers.majority_vote_batch(votes, ncls, self.tie_break, device=self.device)
+        now = time.perf_counter()
         out = []
         for r, q in enumerate(questions):
             w = int(red.winner[r])
@@ -289,16 +290,29 @@ class SelfConsistency:
             out.append(ConsensusResult(
                 question=q, answer=ans, strategy=self.name, rounds=1, member_calls=self.k,
                 unanimous=bool(red.unanimous[r]),
-                latency_s=(handles[r].finished_at or time.perf_counter()) - t0,
+                latency_s=(handles[r][0].finished_at or now) - t0s[r],
                 agreement=float(red.agreement[r]),
                 votes=[{"chain": c, "class": int(votes[r, c])} for c in range(self.k)],
                 extra={"cached_prompt_tokens": cached[r], "chains": chains_text[r]},
-                usage=add_usage({}, [handles[r]]),
+                usage=add_usage({}, handles[r]),
             ))
         return out
 
+    def ask_many(self, questions: Sequence[str]) -> List[ConsensusResult]:
+        t0 = time.perf_counter()
+        handles = [self._submit(q, qi) for qi, q in enumerate(questions)]
+        _run_all([self.member])
+        return self._reduce(questions, handles, [t0] * len(questions))
+
     def ask(self, question: str) -> ConsensusResult:
         return self.ask_many([question])[0]
+
+    @property
+    def members(self) -> List[Member]:
+        return [self.member]
+
+    def pool(self) -> "VotePool":
+        return VotePool(self)
 
 
 class JudgeLogprob:

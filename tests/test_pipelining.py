@@ -118,3 +118,22 @@ def test_vote_pool_answers_match_batch_and_admits_while_running():
     for k in ("prompt_tokens", "completion_tokens"):          # the second pass hits the prefix cache
         assert got[QUESTIONS[0]].usage[k] == batch[0].usage[k]
     assert got[QUESTIONS[0]].usage["cached_tokens"] > 0
+
+
+def test_self_consistency_pool_matches_batch():
+    models = {"m": ModelSpec(name="m", preset="tiny-llama", seed=4)}
+    cfg = ConsensusConfig(strategy="self_consistency", decision_mode="logprob", k_chains=4, models=models,
+                          members=[MemberConfig(name="m", model="m")],
+                          sampling=SamplingConfig(temperature=0.9, top_p=0.95, max_new_tokens=5, seed=3))
+    ens = build_ensemble(cfg, CPU)
+    batch = ens.ask_many(QUESTIONS[:3])
+    pool = ens.strategy.pool()
+    tickets = {pool.submit(q): i for i, q in enumerate(QUESTIONS[:3])}
+    got = {}
+    while pool.active:
+        for t, res in pool.pump():
+            got[tickets[t]] = res
+    for i in range(3):
+        assert got[i].answer == batch[i].answer
+        assert [v["class"] for v in got[i].votes] == [v["class"] for v in batch[i].votes]
+        assert got[i].extra["chains"] == batch[i].extra["chains"]
