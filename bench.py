@@ -89,6 +89,8 @@ def parse_args(argv=None):
     ap.add_argument("--no-mix-decode", action="store_true",
                     help="A, B, C: prefill-only and decode-only steps (decoding chains do not ride along in prefill steps)")
     ap.add_argument("--out", default=None, help="also write the JSON line to this file")
+    ap.add_argument("--skip-spread", action="store_true",
+                    help="multi-GPU runs: skip the extra run of workload A with one model per GPU")
     ap.add_argument("--section-timeout", type=float, default=480.0,
                     help="multi-GPU runs: seconds a sharded workload (D, E) may take before it is abandoned")
     ap.add_argument("--in-child", action="store_true", help=argparse.SUPPRESS)
@@ -471,16 +473,16 @@ def _child_args(argv, letter: str, out_path: str):
         if skip:
             skip = False
             continue
-        if tok in ("--workload", "--out"):
+        if tok in ("--workload", "--out", "--placement"):
             skip = True
             continue
-        if tok.startswith("--workload=") or tok.startswith("--out=") or tok == "--in-child":
+        if tok.startswith(("--workload=", "--out=", "--placement=")) or tok in ("--in-child", "--skip-stream"):
             continue
         keep.append(tok)
     return keep + ["--workload", letter, "--out", out_path, "--in-child"]
 
 
-def run_isolated(ctx: Ctx, a, argv, letter: str):
+def run_isolated(ctx: Ctx, a, argv, letter: str, extra_args=(), pick=None):
     """Multi-GPU runs: a sharded workload (D: tensor-parallel judge, E: expert-parallel MoE) runs
     in child processes, one per rank, with a process group of their own and a time limit. Its
     collectives go through peer-to-peer kernels over IPC-mapped memory; should that path fail or
@@ -504,7 +506,8 @@ def run_isolated(ctx: Ctx, a, argv, letter: str):
         env.update(MASTER_PORT=str(port), MASTER_ADDR="127.0.0.1", **extra)
         log_path = path + f".rank{ctx.rank}.log"
         with open(log_path, "w") as log:
-            p = subprocess.Popen([sys.executable, str(Path(__file__).resolve())] + _child_args(argv, letter, path),
+            p = subprocess.Popen([sys.executable, str(Path(__file__).resolve())] + _child_args(argv, letter, path)
+                                 + list(extra_args),
                                  env=env, stdout=subprocess.DEVNULL, stderr=log, start_new_session=True)
             try:
                 rc = p.wait(a.section_timeout)
@@ -516,8 +519,7 @@ def run_isolated(ctx: Ctx, a, argv, letter: str):
             sec = None
             if lead:
                 full = json.loads(Path(path).read_text())
-                key = {"D": "judge_consensus", "E": "moe_medoid"}[letter]
-                sec = full[key]
+                sec = pick(full) if pick else full[{"D": "judge_consensus", "E": "moe_medoid"}[letter]]
                 sec["collectives"] = label
                 if errors:
                     sec["first_attempt"] = errors
@@ -589,6 +591,17 @@ def main(argv=None) -> int:
         out["vs_baseline"] = round(out["value"] / REFERENCE_BOUND_ANSWERS_PER_S, 1)
     aux_warm = min(a.warmup, 1)
     isolate = ctx.world > 1 and not a.in_child
+    if isolate and "A" in wl and a.placement == "replica" and ctx.world >= len(names) and not a.skip_spread:
+        # The same ensemble with ONE MODEL PER GPU (replicas of len(models) GPUs, the members of a
+        # replica answer concurrently on their own devices and publish their results to each
+        # other): lower latency per question, fewer GPUs busy than with a full ensemble per GPU.
+        def pick(full):
+            return {"metric": full["metric"] + ", one model per GPU", "value": full["value"], "unit": full["unit"],
+                    "ms_per_step": full["ms_per_step"], "steps": full["steps"],
+                    "p50_latency_ms": full.get("p50_latency_ms"), "p95_latency_ms": full.get("p95_latency_ms"),
+                    "global_batch": full["config"]["global_batch"], "placement": full["config"].get("placement")}
+
+        out["ensemble_one_model_per_gpu"] = run_isolated(ctx, a, argv, "A", ("--placement", "spread"), pick)
     if "D" in wl:
         if isolate:
             out["judge_consensus"] = run_isolated(ctx, a, argv, "D")

@@ -96,3 +96,12 @@ def test_isolated_section_reports_which_collectives_it_used():
     assert p.returncode == 0, p.stderr[-3000:]
     out = json_line(p)
     assert out["moe_medoid"]["collectives"].startswith("p2p") and out["value"] == out["moe_medoid"]["value"]
+
+
+def test_three_ranks_also_report_one_model_per_gpu():
+    p = run_bench(["--gpus", "3", "--workload", "A"] + TINY)
+    assert p.returncode == 0, p.stderr[-3000:]
+    out = json_line(p)
+    assert out["n_gpus"] == 3 and out["config"]["global_batch"] == 6          # the headline: a full ensemble per rank
+    sp = out["ensemble_one_model_per_gpu"]
+    assert sp["value"] > 0 and sp["global_batch"] == 2 and sp["placement"]["gpus_per_replica"] == 3
