@@ -389,7 +389,7 @@ class Engine:
     def __init__(self, model: TransformerModel, num_kv_blocks: Optional[int] = None, block_size: int = 64,
                  max_batch_seqs: int = 256, max_prefill_tokens: int = 8192, max_model_len: int = 4096,
                  kv_fraction: float = 0.6, enable_prefix_cache: bool = True, use_graphs: Optional[bool] = None,
-                 graph_buckets: Sequence[int] = (1, 2, 4, 8, 16, 32, 64, 128, 256), max_decision: int = 8,
+                 graph_buckets: Sequence[int] = (1, 2, 4, 8, 16, 32, 64, 128, 256, 512), max_decision: int = 8,
                  max_group_rows: int = 16, name: str = "engine", mix_decode: bool = True,
                  optimistic_admission: bool = False) -> None:
         self.model, self.device, self.name = model, model.device, name
