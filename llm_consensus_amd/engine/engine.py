@@ -432,6 +432,8 @@ class Engine:
         # communicator has no capture story and asking for graphs with it is an error.
         sharded = model.tp_size > 1 or model.ep_size > 1
         capturable = not sharded or bool(getattr(model.comm, "capturable", False))
+        if os.environ.get("CONSENSUS_NO_GRAPHS", "0") == "1":
+            use_graphs = False          # debugging: every launch goes through the ops layer, eagerly
         use_graphs_arg = use_graphs
         if use_graphs is None:
             use_graphs = capturable

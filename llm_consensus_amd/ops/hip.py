@@ -7,6 +7,8 @@ here falls back to PyTorch: a missing library or a non-zero launcher status rais
 from __future__ import annotations
 
 import ctypes
+import os
+import sys
 from ctypes import c_float, c_int, c_longlong, c_void_p
 from typing import Optional
 
@@ -100,10 +102,21 @@ def stop_recording() -> None:
     _recording = None
 
 
+# LC_TRACE_LAUNCHES=1: every launch is announced on stderr before it is issued and the device is
+# synchronised after it, so that when a kernel faults the last line names it (a fault ends the
+# process before anything else can be reported). Debugging aid only: it serialises everything.
+_TRACE = os.environ.get("LC_TRACE_LAUNCHES", "0") == "1"
+
+
 def call(name: str, *args) -> None:
     fn = getattr(lib(), name)
     st = stream()
+    if _TRACE:
+        sys.stderr.write(f"[launch] {name} {[a for a in args if isinstance(a, (int, float))][-10:]}\n")
+        sys.stderr.flush()
     rc = fn(*args, st)
+    if _TRACE and not torch.cuda.is_current_stream_capturing():
+        torch.cuda.synchronize()
     if rc != 0:
         what = "invalid arguments for this kernel" if rc < 0 else f"HIP error {rc}"
         raise KernelLaunchError(f"{name} failed: {what}")

@@ -144,3 +144,25 @@ def test_continuous_batching_mixed_requests_and_decisions():
     e = eng.pop_result(emb).embedding
     assert e.shape == (cfg.hidden_size,) and abs(np.linalg.norm(e) - 1) < 1e-3
     assert eng.stats()["kv.blocks_free"] + eng.stats()["kv.blocks_cached"] == 256
+
+
+def test_step_staging_packs_arrays_of_mixed_dtypes_and_grows():
+    from llm_consensus_amd.engine.engine import _StepStaging
+
+    sg = _StepStaging(torch.device("cpu"))
+    rng = np.random.default_rng(0)
+    for size in (5, 40000):                      # the second round forces the buffers to grow
+        sg.begin()
+        arrays = [rng.integers(-5, 1 << 20, size=size).astype(np.int32),
+                  rng.integers(0, 1 << 40, size=7).astype(np.int64),
+                  rng.random(size=(3, 11)).astype(np.float32),
+                  np.zeros(0, dtype=np.int32),
+                  rng.integers(0, 100, size=(size // 5, 5)).astype(np.int32)]
+        tickets = [sg.put(a) for a in arrays]
+        sg.ship()
+        for t, a in zip(tickets, arrays):
+            v = sg.view(t)
+            assert tuple(v.shape) == a.shape and v.data_ptr() % 16 == 0 or a.size == 0
+            assert np.array_equal(v.numpy(), a)
+    with pytest.raises(TypeError):
+        sg.put(np.zeros(3, dtype=np.float64))
