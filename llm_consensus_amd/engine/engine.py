@@ -344,9 +344,12 @@ class _DecodeGraph:
 class _StepStaging:
     """Host arrays of one prefill step, packed into ONE pinned buffer and shipped with ONE
     asynchronous copy (the decode path has its own fixed-layout arena, _DecodeGraph). ``put``
-    returns a ticket; after ``ship`` the ticket's device view is ``view(ticket)``. The engine has
-    one step in flight and waits for it before planning the next, so both buffers are free
-    again when the next step packs."""
+    returns a ticket; after ``ship`` the ticket's device view is ``view(ticket)``. The device
+    buffer is rewritten by the next step's copy on the same stream, i.e. in order. The PINNED
+    HOST buffer is rewritten by the host: ``begin`` first waits for the previous copy to have
+    read it. A step that samples nothing (prompt chunks that end no prompt, embedding requests)
+    is never waited for by its engine, so without this the next step's packing raced with the
+    copy still in flight and the kernels read block tables and slot maps of two steps mixed."""
 
     _TORCH = {np.dtype(np.int32): torch.int32, np.dtype(np.int64): torch.int64, np.dtype(np.float32): torch.float32}
 
@@ -356,8 +359,11 @@ class _StepStaging:
         self.host = self.dev = None
         self.items: List[tuple] = []
         self.used = 0
+        self.copied: Optional[torch.cuda.Event] = None
 
     def begin(self) -> None:
+        if self.copied is not None:
+            self.copied.synchronize()
         self.items, self.used = [], 0
 
     def put(self, a: np.ndarray) -> int:
@@ -379,6 +385,9 @@ class _StepStaging:
         for off, a in self.items:
             hv[off:off + a.nbytes] = a.reshape(-1).view(np.uint8)
         self.dev[:need].copy_(self.host[:need], non_blocking=True)
+        if self.device.type == "cuda":
+            self.copied = torch.cuda.Event()
+            self.copied.record()
 
     def view(self, ticket: int) -> torch.Tensor:
         off, a = self.items[ticket]

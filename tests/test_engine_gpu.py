@@ -229,3 +229,24 @@ def test_long_prefill_chunks_match_cpu_engine():
     err = np.abs(sc_c - sc_g)
     assert err.max() < 0.15 and err.mean() < 0.05, (err.max(), err.mean())
     assert sum(a[0] == b[0] for a, b in zip(tok_c, tok_g)) >= 2
+
+
+def test_back_to_back_steps_that_sample_nothing_do_not_mix_their_inputs():
+    """Embedding requests spread over many prefill steps: such a step has nothing the host waits
+    for, so the next step is packed while the previous one's input copy may still be in flight.
+    Every embedding must equal the one the same text gets in an engine of its own step."""
+    _, gpu = models("small-llama", seed=5, std=0.1)
+    rng = np.random.default_rng(3)
+    texts = [list(map(int, rng.integers(3, 200, size=int(rng.integers(40, 120))))) for _ in range(96)]
+    many = Engine(gpu, num_kv_blocks=1024, block_size=64, max_prefill_tokens=256, max_batch_seqs=128)
+    rids = [many.submit(t, core.RequestKind.Embed) for t in texts]
+    many.run_until_done()
+    assert many.stats()["prefill.steps"] >= 20
+    got = [many.pop_result(r).embedding for r in rids]
+    one = Engine(gpu, num_kv_blocks=1024, block_size=64, max_prefill_tokens=256, enable_prefix_cache=False)
+    for t, g in zip(texts[::7], got[::7]):
+        r = one.submit(t, core.RequestKind.Embed)
+        one.run_until_done()
+        torch.cuda.synchronize()
+        want = one.pop_result(r).embedding
+        assert np.allclose(g, want, atol=2e-2), float(np.abs(g - want).max())
