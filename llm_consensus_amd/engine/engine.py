@@ -818,7 +818,7 @@ class Engine:
         t_launch = time.perf_counter()
         self.metrics.inc("host.decode_fill_seconds", t_launch - t_fill)
         # ---- run ----
-        if self.use_graphs or self.piecewise:
+        if (self.use_graphs or self.piecewise) and self.model.decode_capturable(bucket):
             if g.graph is None and g.pieces is None:
                 if self.use_graphs:
                     g.capture(self)

@@ -165,6 +165,17 @@ class TransformerModel:
                 lw.down = ops.LinearWeight.from_dense(bf(get(p + "mlp.down_proj.weight")[:, sl]).contiguous(), None, dev)
             self.layers.append(lw)
 
+    def decode_capturable(self, rows: int) -> bool:
+        """Whether a decode step of ``rows`` sequences can be recorded into a hipGraph. The only
+        step that cannot is an expert-parallel all-to-all step whose per-rank share of routed rows
+        exceeds the fixed-capacity exchange (parallel/ep.py): it sizes its buffers from a count it
+        reads back from the device."""
+        if self.ep_size > 1 and self.ep_mode == "a2a" and self.cfg.is_moe:
+            from ..parallel.ep import EP_FIXED_MAX_ROWS
+
+            return -(-rows // self.ep_size) * self.cfg.experts_per_tok <= EP_FIXED_MAX_ROWS
+        return True
+
     @classmethod
     def random_init(cls, cfg: ModelConfig, device, seed: int = 0, tp_rank: int = 0, tp_size: int = 1, comm=None,
                     std: float = 0.02, ep_size: int = 1, ep_mode: str = "allreduce") -> "TransformerModel":

@@ -242,3 +242,17 @@ def test_leader_follower_serving_loop():
     res = run_loopback(3, rank)
     assert res[1] == res[2] == 2                      # followers took part in both batches
     assert res[0][0][0] == res[0][1]
+
+
+def test_only_fixed_capacity_ep_steps_are_graph_capturable():
+    from llm_consensus_amd.models.config import get_preset
+    from llm_consensus_amd.models.transformer import TransformerModel
+    from llm_consensus_amd.parallel.ep import EP_FIXED_MAX_ROWS
+
+    cfg = get_preset("tiny-mixtral")
+    k = cfg.experts_per_tok
+    a2a = TransformerModel.random_init(cfg, torch.device("cpu"), seed=0, ep_size=2, ep_mode="a2a")
+    assert a2a.decode_capturable(2 * EP_FIXED_MAX_ROWS // k)
+    assert not a2a.decode_capturable(2 * EP_FIXED_MAX_ROWS // k + 2)
+    ar = TransformerModel.random_init(cfg, torch.device("cpu"), seed=0, ep_size=2, ep_mode="allreduce")
+    assert ar.decode_capturable(1 << 20)
