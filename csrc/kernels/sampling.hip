@@ -22,7 +22,8 @@ constexpr int kThreads = 1024;
 constexpr int kWaves = kThreads / 64;
 constexpr int kBins = 12;          // threshold-search fan-out per sweep (12 x 1024 floats of LDS)
 constexpr int kGroups = 8;         // groups per wave segment in the draw (see the draw phase)
-constexpr int kSearchPasses = 6;   // 30 / 12^6 ~ 1e-5 resolution in logit/T units
+constexpr int kSearchPasses = 6;    // top-k: 30 / 12^6 ~ 1e-5 resolution in logit/T units (separates the k-th entry)
+constexpr int kSearchPassesP = 4;   // top-p: 30 / 12^4 ~ 1.4e-3; entries that close to the cut carry ~1e-6 of the mass each
 
 struct ArgMax {
   float v;
@@ -145,7 +146,8 @@ __global__ __launch_bounds__(kThreads) void sample_kernel(
     // the first touches its histogram only for the ~1/12 of the candidates still in range.
     float above = 0.f;
     bool hi_is_max = true;
-    for (int it = 0; it < kSearchPasses; ++it) {
+    const int passes = phase == 0 ? kSearchPasses : kSearchPassesP;
+    for (int it = 0; it < passes; ++it) {
       // Per-thread histogram over kBins equal sub-intervals of [lo, hi): thread t owns column t
       // of hist[kBins][kThreads] (conflict-free, no atomics), so suffix sums give the mass (or
       // count) above each threshold t_j = lo + w*j.
