@@ -91,7 +91,7 @@ def parse_args(argv=None):
     ap.add_argument("--out", default=None, help="also write the JSON line to this file")
     ap.add_argument("--skip-spread", action="store_true",
                     help="multi-GPU runs: skip the extra run of workload A with one model per GPU")
-    ap.add_argument("--section-timeout", type=float, default=480.0,
+    ap.add_argument("--section-timeout", type=float, default=420.0,
                     help="multi-GPU runs: seconds a sharded workload (D, E) may take before it is abandoned")
     ap.add_argument("--in-child", action="store_true", help=argparse.SUPPRESS)
     a = ap.parse_args(argv)
@@ -170,10 +170,13 @@ class Ctx:
         if self.world > 1:
             import torch.distributed as dist
 
+            # generous collective timeout: ranks wait for each other across whole isolated sections
+            from datetime import timedelta
+
             if self.cuda:
-                dist.init_process_group("nccl", device_id=self.dev)
+                dist.init_process_group("nccl", device_id=self.dev, timeout=timedelta(minutes=40))
             else:
-                dist.init_process_group("gloo")
+                dist.init_process_group("gloo", timeout=timedelta(minutes=40))
             self.dist = dist
         from llm_consensus_amd.parallel.comm import make_comm
 
