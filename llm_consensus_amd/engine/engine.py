@@ -650,6 +650,15 @@ class Engine:
                           sg.put(np.array(top_k, dtype=np.int32)),
                           sg.put(np.array(seeds, dtype=np.uint64).astype(np.int64)),
                           sg.put(np.array(steps, dtype=np.int32)), sg.put(np.array(ri, dtype=np.int32)))
+        # A sharded model whose step only scores (nothing samples, no riders) exchanges the target
+        # log-probs instead of all-gathering the logits rows.
+        t_score = None
+        if t_need is not None and t_samp is None and m.tp_size > 1:
+            want = self._score_wants(plan)
+            if want:
+                ids_h = self._padded_targets(want)
+                t_score = (want, sg.put(np.array([plan.last_rows[j] for j, _, _ in want], dtype=np.int64)),
+                           sg.put(ids_h))
         sg.ship()
         bt, ctx = sg.view(t_bt), sg.view(t_ctx)
         if n_riders:
@@ -670,44 +679,62 @@ class Engine:
                 st = self._reqs[int(req_ids[i])]
                 st.embed_sum = sums[j] if st.embed_sum is None else st.embed_sum + sums[j]
                 st.embed_count += int(cu[i + 1] - cu[i])
-        toks = lps = logits = None
-        if t_need is not None:
+        toks = lps = logits = scored = None
+        if t_score is not None:
+            self.metrics.inc("prefill.target_only_score_rows", len(t_score[0]))
+            scored = (t_score[0], m.target_logprobs(hidden[sg.view(t_score[1])], sg.view(t_score[2])))
+        elif t_need is not None:
             logits = m.logits(hidden[sg.view(t_need)])
             if t_samp is not None:
                 toks, lps = ops.sample(logits, *(sg.view(t) for t in t_samp))
-        return toks, lps, logits
+        return toks, lps, logits, scored
+
+    def _score_wants(self, plan) -> list:
+        """(index into the step's last rows, request state, target ids) of every prompt that ends
+        in this step and wants log-probs at its last position (Score requests, decision targets)."""
+        want = []
+        for j, seq_i in enumerate(plan.last_row_seq):
+            st = self._reqs[int(plan.request_ids[int(seq_i)])]
+            if st.kind == core.RequestKind.Score and st.score_ids:
+                want.append((j, st, st.score_ids))
+            elif st.kind == core.RequestKind.Generate and st.decision_ids:
+                want.append((j, st, st.decision_ids))
+        return want
+
+    @staticmethod
+    def _padded_targets(want) -> np.ndarray:
+        ids_h = np.zeros((len(want), max(len(ids) for _, _, ids in want)), dtype=np.int32)
+        for i, (_, _, ids) in enumerate(want):
+            ids_h[i, : len(ids)] = ids
+        return ids_h
+
+    @staticmethod
+    def _store_scores(want, vals: np.ndarray) -> None:
+        for i, (_, st, ids) in enumerate(want):
+            v = vals[i, : len(ids)].tolist()
+            if st.kind == core.RequestKind.Score:
+                st.scores = v
+            else:
+                for k in range(st.n):
+                    st.decisions[st.seed + k] = v
 
     def _prefill_finish(self, plan, state) -> None:
-        toks, lps, logits = state
+        toks, lps, logits, scored = state
         req_ids = plan.request_ids
         first_tokens = np.zeros(0, dtype=np.int32)
         first_lps = np.zeros(0, dtype=np.float32)
         if toks is not None:
             first_tokens, first_lps = toks.cpu().numpy(), lps.cpu().numpy()
+        if scored is not None:
+            self._store_scores(scored[0], scored[1].cpu().numpy())
         if logits is not None:
             # decisions / scores at the prompt's last position: one gather over all rows that
             # need one (target lists padded to a common width), one read-back
-            want = []   # (logits row, request state, target ids)
-            for j, seq_i in enumerate(plan.last_row_seq):
-                st = self._reqs[int(req_ids[int(seq_i)])]
-                if st.kind == core.RequestKind.Score and st.score_ids:
-                    want.append((j, st, st.score_ids))
-                elif st.kind == core.RequestKind.Generate and st.decision_ids:
-                    want.append((j, st, st.decision_ids))
+            want = self._score_wants(plan)
             if want:
-                width = max(len(ids) for _, _, ids in want)
-                ids_h = np.zeros((len(want), width), dtype=np.int32)
-                for i, (_, _, ids) in enumerate(want):
-                    ids_h[i, : len(ids)] = ids
                 rows = self._dev(np.array([j for j, _, _ in want], dtype=np.int32))
-                vals = ops.logprob_gather(logits, self._dev(ids_h), rows).cpu().numpy()
-                for i, (_, st, ids) in enumerate(want):
-                    v = vals[i, : len(ids)].tolist()
-                    if st.kind == core.RequestKind.Score:
-                        st.scores = v
-                    else:
-                        for k in range(st.n):
-                            st.decisions[st.seed + k] = v
+                vals = ops.logprob_gather(logits, self._dev(self._padded_targets(want)), rows).cpu().numpy()
+                self._store_scores(want, vals)
             rf = plan.rider_first
             if rf >= 0:
                 # Riders with decision targets: same bookkeeping as a decode step (the newest row

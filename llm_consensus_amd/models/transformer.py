@@ -279,6 +279,26 @@ class TransformerModel:
             lg = self.comm.all_gather_cols(lg, self.cfg.vocab_size)
         return lg
 
+    def target_logprobs(self, hidden_rows: torch.Tensor, ids: torch.Tensor) -> torch.Tensor:
+        """log softmax of the given hidden rows at the listed token ids only: fp32 [R, C] for
+        ``ids`` [R, C]. Under tensor parallelism each rank reduces its own vocabulary shard to
+        C target values plus one log-sum-exp per row and the ranks exchange those C + 1 numbers
+        per row, instead of all-gathering the [R, V] logits (scoring a candidate list needs
+        nothing else: the judge of the reference reads one verdict per answer,
+        /root/reference/src/main.rs:259-291)."""
+        lg = ops.linear(hidden_rows, self.lm_head, out_f32=True)
+        ids = ids.long()
+        if self.tp_size == 1:
+            return lg.gather(1, ids) - torch.logsumexp(lg, dim=-1, keepdim=True)
+        vshard = (self.cfg.vocab_size + self.tp_size - 1) // self.tp_size
+        local = ids - self.tp_rank * vshard
+        mine = (local >= 0) & (local < lg.shape[1])
+        vals = torch.where(mine, lg.gather(1, local.clamp(0, lg.shape[1] - 1)), torch.zeros((), dtype=lg.dtype, device=lg.device))
+        packed = torch.cat([vals, torch.logsumexp(lg, dim=-1, keepdim=True)], dim=1)       # [R, C + 1]
+        parts = self.comm.all_gather_rows(packed).view(self.tp_size, *packed.shape)
+        C = ids.shape[1]
+        return parts[:, :, :C].sum(0) - torch.logsumexp(parts[:, :, C], dim=0).unsqueeze(1)
+
 
 def hf_param_shape(cfg: ModelConfig, name: str) -> Tuple[int, ...]:
     d, Dh = cfg.hidden_size, cfg.head_dim

@@ -109,9 +109,12 @@ class TorchDistComm(Comm):
         return t
 
     def all_gather_cols(self, t: torch.Tensor, total_cols: Optional[int] = None) -> torch.Tensor:
-        parts = [torch.empty_like(t) for _ in range(self.world)]
-        self.dist.all_gather(parts, t.contiguous(), group=self.group)
-        out = torch.cat(parts, dim=-1)
+        # one collective into one buffer [world, ..., C], then one strided copy to [..., world * C]
+        t = t.contiguous()
+        buf = torch.empty((self.world * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+        self.dist.all_gather_into_tensor(buf, t, group=self.group)
+        out = buf.view((self.world,) + tuple(t.shape)).movedim(0, -2).reshape(
+            tuple(t.shape[:-1]) + (self.world * t.shape[-1],))
         return out[..., :total_cols] if total_cols is not None else out
 
     def all_gather_rows(self, t: torch.Tensor) -> torch.Tensor:

@@ -243,6 +243,12 @@ def main() -> None:
         toks = base.all_gather_object(list(got_toks))
         assert all(t == toks[0] for t in toks), "TP ranks sampled different tokens"
         report["tp_tokens_match_unsharded"] = int(sum(a == b for a, b in zip(got_toks, want_toks)))
+        # a step that only scores exchanges target log-probs, not logits rows
+        r = eng.submit(prompt, core.RequestKind.Score, score_ids=targets)
+        eng.run_until_done()
+        assert eng.metrics.counter("prefill.target_only_score_rows") == 1
+        only = np.array(eng.pop_result(r).scores)
+        assert np.allclose(only, want_scores, atol=0.06), (only, want_scores)
         # the bootstrap communicator alone cannot be captured: asking for graphs is an error, not a crash
         plain = TransformerModel.random_init(cfg, DEV, seed=6, std=0.05, tp_rank=rank, tp_size=W, comm=base)
         try:

@@ -57,6 +57,36 @@ def test_tensor_parallel_matches_single(preset):
     assert np.array_equal(res[0][0], res[1][0])
 
 
+def test_score_only_step_of_a_sharded_model_exchanges_targets_not_logits():
+    """A step that only scores sends C + 1 numbers per row between the ranks (target values and
+    a log-sum-exp per vocabulary shard) and never all-gathers logits; the scores equal those of
+    the unsharded model. tiny-qwen's vocabulary does not divide evenly by 3 (ragged last shard)."""
+    cfg = get_preset("tiny-qwen")
+    targets = [1, 65, cfg.vocab_size - 1, 200, 411]
+
+    def scores(model):
+        eng = Engine(model, num_kv_blocks=64, block_size=16, use_graphs=False)
+        rids = [eng.submit(p, core.RequestKind.Score, score_ids=targets[: 5 - (i % 2)]) for i, p in enumerate(PROMPTS)]
+        eng.run_until_done()
+        return [eng.pop_result(r).scores for r in rids], eng.metrics.counter("prefill.target_only_score_rows")
+
+    want, _ = scores(TransformerModel.random_init(cfg, "cpu", seed=5, std=0.08))
+
+    def rank(comm):
+        m = TransformerModel.random_init(cfg, "cpu", seed=5, std=0.08, tp_rank=comm.rank, tp_size=2, comm=comm)
+        gathers = []
+        orig = comm.all_gather_cols
+        comm.all_gather_cols = lambda *a, **k: (gathers.append(1), orig(*a, **k))[1]
+        got, metrics = scores(m)
+        return got, metrics, len(gathers)
+
+    for got, metrics, n_gathers in run_loopback(2, rank):
+        assert n_gathers == 0
+        assert metrics == len(PROMPTS)
+        for g, w in zip(got, want):
+            assert len(g) == len(w) and np.allclose(g, w, atol=0.05), (g, w)
+
+
 @pytest.mark.parametrize("mode", ["allreduce", "a2a"])
 def test_expert_parallel_matches_single(mode):
     cfg = get_preset("tiny-mixtral")
