@@ -93,6 +93,9 @@ def parse_args(argv=None):
                     help="multi-GPU runs: skip the extra run of workload A with one model per GPU")
     ap.add_argument("--section-timeout", type=float, default=420.0,
                     help="multi-GPU runs: seconds a sharded workload (D, E) may take before it is abandoned")
+    ap.add_argument("--isolated-budget", type=float, default=1200.0,
+                    help="multi-GPU runs: seconds all child-process sections together may take; what is left "
+                         "bounds each attempt, and a section that finds less than a minute left is skipped")
     ap.add_argument("--in-child", action="store_true", help=argparse.SUPPRESS)
     a = ap.parse_args(argv)
     wl = ALL_WORKLOADS if a.workload.lower() == "all" else "".join(w.strip().upper() for w in a.workload.split(","))
@@ -502,6 +505,13 @@ def run_isolated(ctx: Ctx, a, argv, letter: str, extra_args=(), pick=None):
     if getattr(ctx, "p2p_failed", False):
         attempts = attempts[1:]                    # an earlier section already found that path unusable here
     for label, extra in attempts:
+        # rank 0's clock decides for everybody, so that all ranks take the same branch
+        left = ctx.comm.broadcast_object(a.isolated_budget - getattr(ctx, "isolated_spent", 0.0) if lead else None, 0)
+        if left < 60.0:
+            errors.append([f"{label}: skipped, {left:.0f} s of --isolated-budget left"])
+            break
+        t_attempt = time.perf_counter()
+        limit = min(a.section_timeout, left)
         port, path = ctx.comm.broadcast_object(
             (_free_port(), os.path.join(tempfile.gettempdir(), f"bench_{letter}_{os.getpid()}_{len(errors)}.json"))
             if lead else None, 0)
@@ -513,11 +523,12 @@ def run_isolated(ctx: Ctx, a, argv, letter: str, extra_args=(), pick=None):
                                  + list(extra_args),
                                  env=env, stdout=subprocess.DEVNULL, stderr=log, start_new_session=True)
             try:
-                rc = p.wait(a.section_timeout)
+                rc = p.wait(limit)
             except subprocess.TimeoutExpired:
                 os.killpg(p.pid, signal.SIGKILL)       # the child's own process group, nothing else
                 p.wait()
                 rc = "timeout"
+        ctx.isolated_spent = getattr(ctx, "isolated_spent", 0.0) + time.perf_counter() - t_attempt
         if ctx.comm.all_true(rc == 0):
             sec = None
             if lead:

@@ -91,6 +91,17 @@ def test_sharded_sections_run_isolated_and_a_failing_one_does_not_take_the_line_
     assert len(err) == 2 and "timeout" in json.dumps(err)
 
 
+def test_isolated_sections_share_one_time_budget():
+    """All child-process sections together get --isolated-budget seconds: with less than a
+    minute of it a section is not started at all, and the line still carries A."""
+    p = run_bench(["--gpus", "2", "--workload", "A,D,E", "--isolated-budget", "30", "--skip-spread"] + TINY)
+    assert p.returncode == 0, p.stderr[-3000:]
+    out = json_line(p)
+    assert out["value"] > 0
+    for key in ("judge_consensus", "moe_medoid"):
+        assert "skipped" in json.dumps(out[key]["error"]), out[key]
+
+
 def test_isolated_section_reports_which_collectives_it_used():
     p = run_bench(["--gpus", "2", "--workload", "E"] + TINY)
     assert p.returncode == 0, p.stderr[-3000:]
