@@ -81,7 +81,8 @@ class ConsensusConfig:
     fixed_proposer: int = 0
     failure_policy: str = "abstain"   # abstain | needs_refinement
     parse_mode: str = "strict"        # strict | tolerant
-    decision_mode: str = "text"       # text | logprob (constrained two-way / choice decision on device)
+    decision_mode: str = "text"       # text | logprob (constrained two-way / choice decision on device) |
+    #                                   tokens (vote strategies: choice read off the reply's token ids on device)
     forward_reasoning_to_refiner: bool = False
     k_chains: int = 16
     samples_per_member: int = 1       # embedding_medoid: candidates sampled per proposer and question
@@ -125,7 +126,7 @@ class ConsensusConfig:
             raise ValueError(f"unknown failure_policy {self.failure_policy!r}")
         if self.parse_mode not in ("strict", "tolerant"):
             raise ValueError(f"unknown parse_mode {self.parse_mode!r}")
-        if self.decision_mode not in ("text", "logprob"):
+        if self.decision_mode not in ("text", "logprob", "tokens"):
             raise ValueError(f"unknown decision_mode {self.decision_mode!r}")
         if self.prompt_layout not in ("reference", "persona_last"):
             raise ValueError(f"unknown prompt_layout {self.prompt_layout!r}")

@@ -134,6 +134,12 @@ class Backend:
         scripted backends); lets a driver overlap the steps of several engines."""
         return []
 
+    def token_ids_of(self, text: str) -> Optional[List[int]]:
+        """Token ids of ``text`` in this backend's vocabulary (no BOS), or None when the backend
+        has no tokenizer of its own (remote, scripted). Strategies that classify answers at the
+        token level (``decision_mode="tokens"``) fall back to the text parser on None."""
+        return None
+
     def stats(self) -> Dict[str, float]:
         return {}
 

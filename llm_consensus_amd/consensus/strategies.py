@@ -30,7 +30,7 @@ from .._native import core
 from ..utils.log import get_logger
 from ..utils.trace import span
 from . import reducers
-from .backend import BackendError, BackendStepper, GenParams, add_usage, run_backends
+from .backend import BackendError, BackendStepper, GenParams, GenResult, add_usage, run_backends
 from .members import Member, distinct_backends
 from .protocol import ConsensusResult
 
@@ -97,19 +97,62 @@ def _classify(text: str, decision_lp: Optional[List[float]], choices: str) -> in
     return core.extract_choice(text, choices)
 
 
+def _classify_tokens(backend, results: Sequence[Optional["GenResult"]], choices: str, cue: str, window: int,
+                     device) -> Optional[np.ndarray]:
+    """Token-level classification of every chain of ``results`` (None = failed call) with the
+    ``answer_extract`` reducer (device kernel on a GPU): the class of the first choice token
+    within ``window`` tokens after the last occurrence of the cue's token sequence. Returns
+    int32 [rows] in result/chain order, -1 where the cue or a choice token is missing, or None
+    when the backend has no tokenizer or returns no token ids (the caller parses text instead).
+    The reference reads a verdict off the first line of the reply text
+    (/root/reference/src/main.rs:139-153); this is the same decision taken on token ids, without
+    detokenising thousands of chains."""
+    marker = backend.token_ids_of(cue) if cue else []
+    if marker is None:
+        return None
+    # a choice letter is tokenised differently after a space and after a colon / newline: both forms count
+    forms: List[List[int]] = []
+    for c in choices:
+        ids = {t[-1] for t in (backend.token_ids_of(" " + c), backend.token_ids_of(c)) if t}
+        forms.append(sorted(ids))
+    rows = [ids for res in results if res is not None for ids in res.token_ids]
+    if not rows:
+        return None
+    L = max(1, max(len(r) for r in rows))
+    ids = np.zeros((len(rows), L), dtype=np.int32)
+    lens = np.zeros(len(rows), dtype=np.int32)
+    for i, r in enumerate(rows):
+        ids[i, :len(r)] = r
+        lens[i] = len(r)
+    out = np.full(len(rows), -1, dtype=np.int32)
+    # one pass per tokenisation form; the first form that finds a class for a row keeps it
+    for k in range(max(len(f) for f in forms)):
+        choice_ids = [f[min(k, len(f) - 1)] if f else -1 for f in forms]
+        got = reducers.answer_extract(ids, lens, marker, choice_ids, window, device=device)
+        out = np.where(out < 0, got, out)
+    return out
+
+
 class MajorityVote:
     name = "majority_vote"
 
     def __init__(self, members: Sequence[Member], choices: str = "ABCD",
                  tie_break: "core.TieBreak" = core.TieBreak.LowestClass,
                  decision_mode: str = "text", params: Optional[GenParams] = None,
-                 prompt_fn: Optional[Callable[[str], str]] = None, device=None) -> None:
+                 prompt_fn: Optional[Callable[[str], str]] = None, device=None,
+                 answer_cue: str = "Answer:", cue_window: int = 4) -> None:
+        """``decision_mode``: "text" parses the reply text, "logprob" compares the log-probabilities
+        of the choice tokens after the reply, "tokens" scans the reply's token ids for the first
+        choice token after ``answer_cue`` (rows without a hit fall back to the text parser)."""
         if not members:
             raise ValueError("MajorityVote needs at least one member")
+        if decision_mode not in ("text", "logprob", "tokens"):
+            raise ValueError(f"unknown decision_mode {decision_mode!r}")
         self.members = list(members)
         self.choices = choices
         self.tie_break = tie_break
         self.decision_mode = decision_mode
+        self.answer_cue, self.cue_window = answer_cue, cue_window
         self.params = params
         self.prompt_fn = prompt_fn or (lambda q: q)
         self.device = device
@@ -128,16 +171,30 @@ class MajorityVote:
         R, N = len(questions), len(self.members)
         votes = np.full((R, N), -1, dtype=np.int32)
         texts = [[""] * N for _ in range(R)]
+        results: List[List[Optional[GenResult]]] = [[None] * N for _ in range(R)]
         for r in range(R):
             for i in range(N):
                 try:
-                    res = handles[r][i].result()
+                    results[r][i] = handles[r][i].result()
                 except BackendError as e:
                     log.error("%s failed: %s", self.members[i].name, e)
+        if self.decision_mode == "tokens":
+            # one extraction launch per member (members differ in vocabulary), all questions at once
+            for i, m in enumerate(self.members):
+                col = [results[r][i] for r in range(R)]
+                got = _classify_tokens(m.backend, col, self.choices, self.answer_cue, self.cue_window, self.device)
+                if got is not None:
+                    rows = [r for r in range(R) if col[r] is not None]
+                    votes[rows, i] = got[:len(rows)]
+        for r in range(R):
+            for i in range(N):
+                res = results[r][i]
+                if res is None:
                     continue
                 texts[r][i] = res.texts[0]
-                dec = res.decision_logprobs[0] if res.decision_logprobs else None
-                votes[r, i] = _classify(res.texts[0], dec, self.choices)
+                if votes[r, i] < 0:
+                    dec = res.decision_logprobs[0] if res.decision_logprobs else None
+                    votes[r, i] = _classify(res.texts[0], dec, self.choices)
         # Member weights (MemberConfig.weight): all equal => a plain plurality.
         w = np.array([float(getattr(m, "weight", 1.0)) for m in self.members], dtype=np.float32)
         weights = w if (w != w[0]).any() else None
@@ -229,7 +286,10 @@ class SelfConsistency:
                  tie_break: "core.TieBreak" = core.TieBreak.LowestClass,
                  decision_mode: str = "text", params: Optional[GenParams] = None,
                  prompt_fn: Optional[Callable[[str], str]] = None, numeric: bool = False,
-                 device=None) -> None:
+                 device=None, answer_cue: str = "Answer:", cue_window: int = 4) -> None:
+        if decision_mode not in ("text", "logprob", "tokens"):
+            raise ValueError(f"unknown decision_mode {decision_mode!r}")
+        self.answer_cue, self.cue_window = answer_cue, cue_window
         self.member = member
         self.k = k_chains
         self.choices = choices
@@ -254,11 +314,26 @@ class SelfConsistency:
         labels: List[List[str]] = [[] for _ in range(R)]  # class id -> answer string (free-form mode)
         chains_text: List[List[str]] = [[] for _ in range(R)]
         cached = [0] * R
+        results: List[Optional[GenResult]] = [None] * R
         for r in range(R):
             try:
-                res = handles[r][0].result()
+                results[r] = handles[r][0].result()
             except BackendError as e:
                 log.error("%s failed: %s", self.member.name, e)
+        if self.decision_mode == "tokens" and not self.numeric:
+            # every chain of every question in one extraction launch
+            got = _classify_tokens(self.member.backend, results, self.choices, self.answer_cue, self.cue_window,
+                                   self.device)
+            if got is not None:
+                at = 0
+                for r in range(R):
+                    if results[r] is not None:
+                        n = len(results[r].token_ids)
+                        votes[r, :min(n, self.k)] = got[at:at + min(n, self.k)]
+                        at += n
+        for r in range(R):
+            res = results[r]
+            if res is None:
                 continue
             cached[r] = res.cached_tokens
             chains_text[r] = list(res.texts)
@@ -271,7 +346,7 @@ class SelfConsistency:
                     if key not in labels[r]:
                         labels[r].append(key)
                     votes[r, c] = labels[r].index(key)
-                else:
+                elif votes[r, c] < 0:
                     dec = res.decision_logprobs[c] if res.decision_logprobs else None
                     votes[r, c] = _classify(text, dec, self.choices)
         ncls = max(len(self.choices), max((len(l) for l in labels), default=0), 1)

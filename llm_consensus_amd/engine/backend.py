@@ -57,6 +57,9 @@ class EngineBackend(Backend):
             h.set_error(e)
         return h
 
+    def token_ids_of(self, text: str):
+        return list(self.tok.encode(text, add_bos=False))
+
     def submit_score(self, prompt: str, targets: Sequence[str]) -> Handle:
         h = Handle()
         try:

@@ -160,6 +160,17 @@ def test_strategies_end_to_end_on_gpu_backend():
     res = SelfConsistency(members[0], k_chains=8, decision_mode="logprob", device="cuda").ask_many(qs[:2])
     assert all(r.answer in "ABCD" and len(r.votes) == 8 for r in res)
     assert res[0].extra["cached_prompt_tokens"] >= 0
+    # token-level decisions: the reply's token ids are scanned on the device (answer_extract
+    # kernel); rows without a cue fall back to the text parser, so the votes must equal those of a
+    # run that only parses text (same seeds, same chains)
+    tok = MajorityVote(members, decision_mode="tokens", device="cuda", answer_cue="").ask_many(qs)
+    txt = MajorityVote(members, decision_mode="text", device="cuda").ask_many(qs)
+    assert [[v["text"] for v in r.votes] for r in tok] == [[v["text"] for v in r.votes] for r in txt]
+    for a, b in zip(tok, txt):
+        for va, vb in zip(a.votes, b.votes):
+            letters = [c for c in va["text"] if c in "ABCD"]
+            # with an empty cue the kernel returns the LAST choice token of the reply
+            assert va["class"] == ("ABCD".index(letters[-1]) if letters else vb["class"])
     res = JudgeLogprob(members[:2], [members[2]], params=gp, device="cuda").ask_many(qs[:2])
     assert all(r.proposer in (personas[0].name, personas[1].name) for r in res)
     res = EmbeddingMedoid(members[:3], members[0], params=gp, device="cuda").ask_many(qs[:2])

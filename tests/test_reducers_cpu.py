@@ -97,3 +97,48 @@ def test_member_weights_flip_a_two_to_one_vote():
     for m in members:
         m.weight = 1.0
     assert MajorityVote(members).ask("Which? A) a B) b C) c D) d").answer == "B"
+
+
+def test_token_level_decisions_in_the_vote_strategies():
+    """decision_mode="tokens": answers are classified from token ids with answer_extract (the first
+    choice token after the cue), rows without the cue fall back to the text parser, and a backend
+    without a tokenizer is parsed as text throughout."""
+    from llm_consensus_amd.consensus.backend import Backend, GenParams, GenResult, Handle
+    from llm_consensus_amd.consensus.members import Member
+    from llm_consensus_amd.consensus.strategies import MajorityVote, SelfConsistency
+    from llm_consensus_amd.utils.tokenizer import ByteLevelTokenizer
+
+    class Canned(Backend):
+        def __init__(self, replies, with_tokens=True):
+            self.replies, self.tok, self.with_tokens, self.pending = replies, ByteLevelTokenizer(), with_tokens, []
+
+        def token_ids_of(self, text):
+            return list(self.tok.encode(text, add_bos=False)) if self.with_tokens else None
+
+        def submit_generate(self, prompt, params, on_text=None):
+            h = Handle()
+            texts = [self.replies[(len(self.pending) + c) % len(self.replies)] for c in range(params.n)]
+            self.pending.append((h, texts))
+            return h
+
+        def run(self):
+            for h, texts in self.pending:
+                ids = [list(self.tok.encode(t, add_bos=False)) for t in texts] if self.with_tokens else []
+                h.set_result(GenResult(texts=texts, token_ids=ids))
+            self.pending = []
+
+    personas = core.default_personas()
+    # "B ... Answer: C": the text parser and the token scan must both pick what follows the cue
+    replies = ["I think B at first. Answer: C", "Answer:D", "The answer is (A).", "Answer: zzzz"]
+    gp = GenParams(max_new_tokens=8)
+    for with_tokens in (True, False):
+        members = [Member(personas[i], Canned(replies[i:] + replies[:i], with_tokens), params=gp) for i in range(3)]
+        res = MajorityVote(members, decision_mode="tokens").ask_many(["q0"])[0]
+        want = [core.extract_choice(replies[i], "ABCD") for i in range(3)]
+        assert [v["class"] for v in res.votes] == want == [2, 3, 0]
+    sc = SelfConsistency(Member(personas[0], Canned(replies), params=gp), k_chains=4, decision_mode="tokens")
+    out = sc.ask_many(["q0", "q1"])
+    assert [v["class"] for v in out[0].votes] == [2, 3, 0, -1]
+    assert [v["class"] for v in out[1].votes] == [3, 0, -1, 2]
+    with pytest.raises(ValueError):
+        MajorityVote(members, decision_mode="nope")
