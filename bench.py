@@ -71,6 +71,9 @@ def parse_args(argv=None):
     ap.add_argument("--skip-stream", action="store_true", help="skip the standing-queue run of workload A")
     ap.add_argument("--in-flight", type=int, default=0,
                     help="questions kept in flight per GPU in the standing-queue run (default 4 x --questions)")
+    ap.add_argument("--poisson-load", type=float, default=0.7,
+                    help="open-loop run of workload A: arrival rate as a fraction of the closed-loop rate (0 = skip)")
+    ap.add_argument("--poisson-seconds", type=float, default=10.0, help="length of the arrival trace")
     ap.add_argument("--aux-steps", type=int, default=None, help="timed steps of C, D, E (default: min(steps, 6))")
     ap.add_argument("--proto-questions", type=int, default=8, help="questions per GPU per step (workload C)")
     ap.add_argument("--proto-prompt-len", type=int, default=128)
@@ -341,6 +344,46 @@ def run_replica_workloads(ctx: Ctx, out: dict) -> None:
                 "p50_latency_ms": pct(lat_s, 50), "p95_latency_ms": pct(lat_s, 95),
                 "preemptions": int(sum(m.backend.stats().get("sched.preemptions", 0) for m in members)),
             }
+            if a.poisson_load > 0:
+                # Open loop: questions arrive as a Poisson process at a fraction of the closed-loop
+                # rate just measured (each rank draws its own arrival trace), are admitted the moment
+                # they arrive, and their latency counts from the ARRIVAL, so time spent waiting for
+                # the driver to come round is included. This is the latency a client sees when the
+                # service is busy but not saturated.
+                rate = a.poisson_load * (n_s / el_s) / ctx.world           # arrivals per second and rank
+                n_open = max(8, int(min(a.poisson_seconds * rate, 4 * n_sq)))
+                arrive = np.cumsum(rng.exponential(1.0 / rate, size=n_open))
+                qs = make_questions(rng, n_open, a.prompt_len)
+                pool = vote.pool()
+                comm.barrier()
+                ctx.sync()
+                t0 = time.perf_counter()
+                lat_o, late, res_o, nxt, peak = [], {}, [], 0, 0
+                while nxt < n_open or pool.active:
+                    now = time.perf_counter() - t0
+                    while nxt < n_open and arrive[nxt] <= now:
+                        late[pool.submit(qs[nxt])] = now - arrive[nxt]
+                        nxt += 1
+                    peak = max(peak, pool.active)
+                    if pool.active:
+                        for tk, r in pool.pump():
+                            res_o.append(r)
+                            lat_o.append((r.latency_s + late.pop(tk)) * 1e3)
+                    else:
+                        time.sleep(min(1e-3, max(0.0, arrive[nxt] - now)))
+                k_o = winners(res_o)
+                ctx.sync()
+                comm.barrier()
+                el_o = comm.max_float(time.perf_counter() - t0)
+                lat_o = comm.gather_floats(lat_o)
+                out["poisson_arrivals"] = {
+                    "mode": "open loop: Poisson arrivals, latency from arrival to answer",
+                    "load_fraction_of_closed_loop_rate": a.poisson_load,
+                    "offered_rate_per_s": round(rate * ctx.world, 2), "questions_per_gpu": n_open,
+                    "value": round(k_o / el_o, 3), "unit": "answers/s",
+                    "p50_latency_ms": pct(lat_o, 50), "p95_latency_ms": pct(lat_o, 95),
+                    "p99_latency_ms": pct(lat_o, 99), "peak_in_flight_per_gpu": int(peak),
+                }
     if "B" in wl:
         sc = SelfConsistency(members[0], k_chains=a.k_chains, choices="ABCD", decision_mode="logprob",
                              device=dev if ctx.cuda else None)

@@ -57,6 +57,21 @@ def test_single_rank_line_has_every_section_and_the_contract_fields():
     assert out["judge_consensus"]["judge_tp"] == 1 and out["moe_medoid"]["expert_parallel"] == 1
 
 
+def test_closed_loop_and_poisson_arrival_sections_of_workload_a():
+    """Workload A as a service: the closed loop (a finished question is replaced at once) and the
+    open loop with Poisson arrivals at 70 % of the closed-loop rate, whose latencies count from the
+    arrival and whose achieved rate cannot exceed the offered one by more than the trace's noise."""
+    args = [x for x in TINY if x != "--skip-stream"] + ["--workload", "A", "--in-flight", "4", "--poisson-seconds", "1.5"]
+    p = run_bench(args)
+    assert p.returncode == 0, p.stderr[-3000:]
+    out = json_line(p)
+    sq, po = out["standing_queue"], out["poisson_arrivals"]
+    assert sq["value"] > 0 and sq["questions_in_flight_per_gpu"] == 4
+    assert po["questions_per_gpu"] >= 8 and po["value"] > 0
+    assert po["p50_latency_ms"] > 0 and po["p99_latency_ms"] >= po["p95_latency_ms"] >= po["p50_latency_ms"]
+    assert po["value"] < 2.0 * po["offered_rate_per_s"]
+
+
 def test_spread_placement_puts_one_model_per_rank():
     p = run_bench(["--gpus", "3", "--workload", "A", "--placement", "spread"] + TINY)
     assert p.returncode == 0, p.stderr[-3000:]
