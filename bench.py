@@ -99,6 +99,10 @@ def parse_args(argv=None):
     ap.add_argument("--isolated-budget", type=float, default=1200.0,
                     help="multi-GPU runs: seconds all child-process sections together may take; what is left "
                          "bounds each attempt, and a section that finds less than a minute left is skipped")
+    ap.add_argument("--share-gpu", action="store_true",
+                    help="rehearsal on a one-GPU machine: all --gpus ranks use GPU 0, the process group is gloo with "
+                         "host-staged tensors (RCCL refuses two ranks on one device), model groups still use the "
+                         "peer-to-peer kernels over IPC-mapped memory. Not a measurement: the ranks share the GPU")
     ap.add_argument("--in-child", action="store_true", help=argparse.SUPPRESS)
     a = ap.parse_args(argv)
     wl = ALL_WORKLOADS if a.workload.lower() == "all" else "".join(w.strip().upper() for w in a.workload.split(","))
@@ -120,7 +124,7 @@ def _free_port() -> int:
 def launch(a, argv) -> int:
     """Starts one child per GPU. Runs before this process has made any GPU call and never
     replaces a process: the children are fresh interpreters."""
-    if a.device == "cuda":
+    if a.device == "cuda" and not a.share_gpu:
         import torch
 
         seen = torch.cuda.device_count()          # counts devices without creating a context
@@ -165,6 +169,8 @@ class Ctx:
             if not torch.cuda.is_available():
                 raise SystemExit("bench.py needs a GPU (torch.cuda.is_available() is False); --device cpu is the "
                                  "plumbing mode")
+            if a.share_gpu:
+                local = 0
             if torch.cuda.device_count() <= local:
                 raise SystemExit(f"bench.py: rank {self.rank} wants GPU {local}, {torch.cuda.device_count()} visible")
             torch.cuda.set_device(local)
@@ -179,7 +185,7 @@ class Ctx:
             # generous collective timeout: ranks wait for each other across whole isolated sections
             from datetime import timedelta
 
-            if self.cuda:
+            if self.cuda and not a.share_gpu:
                 dist.init_process_group("nccl", device_id=self.dev, timeout=timedelta(minutes=40))
             else:
                 dist.init_process_group("gloo", timeout=timedelta(minutes=40))
@@ -624,6 +630,8 @@ def main(argv=None) -> int:
         },
         "workloads": wl,
     }
+    if a.share_gpu:
+        out["rehearsal"] = f"{ctx.world} ranks share ONE GPU (gloo process group, host-staged tensors): not a measurement"
     samp = W.sampling(a.temperature, a.top_p, a.new_tokens)
     if "A" in wl and a.placement == "spread":
         if ctx.world < len(names):

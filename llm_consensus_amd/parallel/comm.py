@@ -101,49 +101,69 @@ class TorchDistComm(Comm):
         self.dist, self.device, self.group = dist, device, group
         # only RCCL enqueues its collectives on the stream; gloo stages through the host
         self.capturable_thread_local = str(dist.get_backend(group)).lower() == "nccl"
+        # gloo group, tensors on a GPU (several ranks rehearsing on one device, where RCCL refuses to
+        # start): every collective goes through host copies of its operands
+        self.staged = not self.capturable_thread_local and torch.device(device).type == "cuda"
         self.rank = dist.get_rank(group)
         self.world = dist.get_world_size(group)
 
+    def _in(self, t: torch.Tensor) -> torch.Tensor:
+        return t.cpu() if (self.staged and t.is_cuda) else t
+
+    def _out(self, h: torch.Tensor, like: torch.Tensor) -> torch.Tensor:
+        return h.to(like.device) if h.device != like.device else h
+
     def all_reduce(self, t: torch.Tensor) -> torch.Tensor:
-        self.dist.all_reduce(t, group=self.group)
+        h = self._in(t)
+        self.dist.all_reduce(h, group=self.group)
+        if h is not t:
+            t.copy_(h)
         return t
 
     def all_gather_cols(self, t: torch.Tensor, total_cols: Optional[int] = None) -> torch.Tensor:
         # one collective into one buffer [world, ..., C], then one strided copy to [..., world * C]
         t = t.contiguous()
-        buf = torch.empty((self.world * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
-        self.dist.all_gather_into_tensor(buf, t, group=self.group)
+        h = self._in(t)
+        buf = torch.empty((self.world * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=h.device)
+        self.dist.all_gather_into_tensor(buf, h, group=self.group)
+        buf = self._out(buf, t)
         out = buf.view((self.world,) + tuple(t.shape)).movedim(0, -2).reshape(
             tuple(t.shape[:-1]) + (self.world * t.shape[-1],))
         return out[..., :total_cols] if total_cols is not None else out
 
     def all_gather_rows(self, t: torch.Tensor) -> torch.Tensor:
         t = t.contiguous()
-        out = torch.empty((self.world * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
-        self.dist.all_gather_into_tensor(out, t, group=self.group)
-        return out
+        h = self._in(t)
+        out = torch.empty((self.world * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=h.device)
+        self.dist.all_gather_into_tensor(out, h, group=self.group)
+        return self._out(out, t)
 
     def broadcast(self, t: torch.Tensor, src: int = 0) -> torch.Tensor:
-        self.dist.broadcast(t, src=self._global(src), group=self.group)
+        h = self._in(t)
+        self.dist.broadcast(h, src=self._global(src), group=self.group)
+        if h is not t:
+            t.copy_(h)
         return t
 
     def all_to_all_rows(self, t: torch.Tensor, send_counts: Sequence[int], recv_counts: Sequence[int]) -> torch.Tensor:
-        out = torch.empty((int(sum(recv_counts)),) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
-        self.dist.all_to_all_single(out, t.contiguous(), list(map(int, recv_counts)), list(map(int, send_counts)),
+        h = self._in(t.contiguous())
+        out = torch.empty((int(sum(recv_counts)),) + tuple(t.shape[1:]), dtype=t.dtype, device=h.device)
+        self.dist.all_to_all_single(out, h, list(map(int, recv_counts)), list(map(int, send_counts)),
                                     group=self.group)
-        return out
+        return self._out(out, t)
 
     def all_to_all_equal(self, t: torch.Tensor) -> torch.Tensor:
         t = t.contiguous()
-        out = torch.empty_like(t)
-        self.dist.all_to_all_single(out, t, group=self.group)
-        return out
+        h = self._in(t)
+        out = torch.empty_like(h)
+        self.dist.all_to_all_single(out, h, group=self.group)
+        return self._out(out, t)
 
     def barrier(self) -> None:
         self.dist.barrier(group=self.group)
 
     def max_float(self, x: float) -> float:
-        t = torch.tensor([x], dtype=torch.float64, device=self.device)
+        t = torch.tensor([x], dtype=torch.float64, device="cpu" if self.staged else self.device)
         self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX, group=self.group)
         return float(t.item())
 
@@ -153,7 +173,7 @@ class TorchDistComm(Comm):
         return [x for part in objs for x in (part or [])]
 
     def all_true(self, flag: bool) -> bool:
-        t = torch.tensor([1 if flag else 0], dtype=torch.int32, device=self.device)
+        t = torch.tensor([1 if flag else 0], dtype=torch.int32, device="cpu" if self.staged else self.device)
         self.dist.all_reduce(t, op=self.dist.ReduceOp.MIN, group=self.group)
         return bool(t.item())
 
@@ -162,7 +182,8 @@ class TorchDistComm(Comm):
 
     def broadcast_object(self, obj, src: int = 0):
         box = [obj if self.rank == src else None]
-        self.dist.broadcast_object_list(box, src=self._global(src), group=self.group, device=self.device)
+        self.dist.broadcast_object_list(box, src=self._global(src), group=self.group,
+                                        device=torch.device("cpu") if self.staged else self.device)
         return box[0]
 
     def all_gather_object(self, obj) -> list:

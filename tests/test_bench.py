@@ -131,3 +131,22 @@ def test_three_ranks_also_report_one_model_per_gpu():
     assert out["n_gpus"] == 3 and out["config"]["global_batch"] == 6          # the headline: a full ensemble per rank
     sp = out["ensemble_one_model_per_gpu"]
     assert sp["value"] > 0 and sp["global_batch"] == 2 and sp["placement"]["gpus_per_replica"] == 3
+
+
+@pytest.mark.gpu
+def test_two_ranks_rehearse_every_workload_on_one_gpu():
+    """--share-gpu: the multi-GPU code paths of bench.py on a one-GPU machine. Two ranks (child
+    processes) use GPU 0; the replica workloads exchange winners through the host-staged gloo
+    group, D runs its judge tensor-parallel over both ranks and E its experts expert-parallel with
+    all-to-all dispatch, both through the peer-to-peer kernels over IPC-mapped memory and inside
+    isolated child processes, as on a real node."""
+    args = [x for x in TINY if x not in ("--device", "cpu")] + ["--gpus", "2", "--share-gpu", "--workload", "A,B,D,E",
+                                                                 "--skip-spread"]
+    p = run_bench(args, env={"HSA_ENABLE_IPC_MODE_LEGACY": "0"}, timeout=420)
+    assert p.returncode == 0, p.stderr[-3000:]
+    out = json_line(p)
+    assert out["n_gpus"] == 2 and "rehearsal" in out and out["value"] > 0
+    d, e = out["judge_consensus"], out["moe_medoid"]
+    assert d.get("value", 0) > 0 and d["judge_tp"] == 2, d
+    assert e.get("value", 0) > 0 and e["expert_parallel"] == 2 and e["ep_mode"] == "a2a", e
+    assert d["collectives"].startswith("p2p") and e["collectives"].startswith("p2p")
