@@ -90,7 +90,8 @@ def build_selftest(sanitize: str = "address,undefined") -> Path:
 
 def build_kernels(force: bool = False, jobs: int = 8) -> Path:
     src_dir = ROOT / "csrc" / "kernels"
-    srcs = sorted(src_dir.glob("*.hip"))
+    # the device runtime (host code over the HIP runtime API) lives in the same library
+    srcs = sorted(src_dir.glob("*.hip")) + sorted((ROOT / "csrc" / "runtime").glob("*.hip"))
     hdrs = sorted(src_dir.glob("*.h")) + sorted(src_dir.glob("*.hpp")) + sorted(src_dir.glob("*.cuh"))
     obj_dir = BUILD_DIR / "kernels"
     obj_dir.mkdir(parents=True, exist_ok=True)
