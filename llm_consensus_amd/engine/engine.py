@@ -19,6 +19,7 @@ import numpy as np
 import torch
 
 from .. import ops
+from .. import runtime as rt
 from .._native import core
 from ..models.transformer import AttnMeta, KVCache, TransformerModel
 from ..utils.log import get_logger
@@ -98,13 +99,20 @@ class _DecodeGraph:
                   ("decision_ids", B * C), ("group_first", G), ("group_count", G), ("group_shared", G),
                   ("block_tables", B * MB)]
         total = sum(n for _, n in fields)
-        self.arena = torch.zeros(total, dtype=torch.int32, device=dev)
-        self.host = torch.zeros(total, dtype=torch.int32)
         if dev.type == "cuda":
-            self.host = self.host.pin_memory()
+            # device block and pinned host mirror from the engine's runtime arenas
+            self.arena = eng.rt.small.tensor((total,), torch.int32)
+            self.arena.zero_()
+            hnp = eng.rt.pinned.array((total,), np.int32)
+            hnp[:] = 0
+            self.host = None
+        else:
+            self.arena = torch.zeros(total, dtype=torch.int32, device=dev)
+            self.host = torch.zeros(total, dtype=torch.int32)
+            hnp = self.host.numpy()
+        self.host_np = hnp
         self.h: Dict[str, np.ndarray] = {}
         off = 0
-        hnp = self.host.numpy()
         for name, n in fields:
             d, hv = self.arena[off:off + n], hnp[off:off + n]
             if name == "seeds":
@@ -125,21 +133,32 @@ class _DecodeGraph:
         # the whole prompt alone is a chain of dependent loads, so the prompt is cut into ~128-key
         # pieces. Blocks of the (statically sized) group slots that are empty at run time exit at once.
         self.prefix_splits = max(1, min(8, ctx_class // 128))
-        self.graph: Optional[torch.cuda.CUDAGraph] = None
+        self.graph: Optional[int] = None      # key of the step's hipGraph in the engine's graph cache
         self.pieces: Optional[List[tuple]] = None
         self.lists = False
         self.out_tokens = self.out_lps = self.out_dec = None
-        # pinned landing buffers of the step's results, and the row -> request map the host
-        # mirror was last filled for
-        pin = dev.type == "cuda"
-        self.res_tok = torch.zeros(B, dtype=torch.int32, pin_memory=pin)
-        self.res_lp = torch.zeros(B, dtype=torch.float32, pin_memory=pin)
-        self.res_dec = torch.zeros(B, C, dtype=torch.float32, pin_memory=pin)
+        # pinned landing buffers of the step's results (numpy views of pinned arena memory; plain
+        # arrays on the CPU), and the row -> request map the host mirror was last filled for
+        if dev.type == "cuda":
+            self.res_tok = eng.rt.pinned.array((B,), np.int32)
+            self.res_lp = eng.rt.pinned.array((B,), np.float32)
+            self.res_dec = eng.rt.pinned.array((B, C), np.float32)
+            self.done = rt.Event()
+        else:
+            self.res_tok = np.zeros(B, dtype=np.int32)
+            self.res_lp = np.zeros(B, dtype=np.float32)
+            self.res_dec = np.zeros((B, C), dtype=np.float32)
+            self.done = None
         self.rows_key: Optional[np.ndarray] = None
         self.any_decision = False
+        self._graphs = eng.rt.graphs if dev.type == "cuda" else None
 
     def upload(self) -> None:
-        self.arena.copy_(self.host, non_blocking=True)
+        """The host mirror goes to the device block with one asynchronous copy on the step's stream."""
+        if self.host is None:
+            rt.copy_async(self.arena.data_ptr(), self.host_np.ctypes.data, self.host_np.nbytes, rt.H2D)
+        else:
+            self.arena.copy_(self.host)
 
     def meta(self, eng: "Engine") -> AttnMeta:
         return AttnMeta(
@@ -156,21 +175,17 @@ class _DecodeGraph:
         return tok, lp, dec
 
     def capture(self, eng: "Engine") -> None:
-        # warm-up on a side stream (allocator + lazy init), then capture
-        s = torch.cuda.Stream(device=eng.device)
-        s.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(s):
-            self.run_body(eng)
-        torch.cuda.current_stream().wait_stream(s)
+        """Records the step into the engine's graph cache (runtime.GraphCache: thread-local stream
+        capture, so HIP calls made meanwhile by other threads -- RCCL's watchdog, the HTTP front
+        end, another engine's loopback rank -- do not invalidate it; tensors allocated while
+        recording come from the cache's private pool and keep their addresses)."""
+        self.run_body(eng)                          # warm-up: allocator, lazy init, peer channels
         torch.cuda.synchronize()
-        g = torch.cuda.CUDAGraph()
-        # thread_local: HIP calls made by other threads while this one captures (RCCL's watchdog,
-        # the HTTP front end, another engine's loopback rank) must not invalidate the capture.
-        with torch.cuda.graph(g, pool=eng.graph_pool, capture_error_mode="thread_local"):
-            self.out_tokens, self.out_lps, self.out_dec = self.run_body(eng)
-        self.graph = g
-        if eng.graph_pool is None:
-            eng.graph_pool = g.pool()
+        key = eng.rt.new_key()
+        with eng._capture_stream():
+            with self._graphs.capture(key):
+                self.out_tokens, self.out_lps, self.out_dec = self.run_body(eng)
+        self.graph = key
 
     def capture_piecewise(self, eng: "Engine") -> None:
         """Tensor-parallel decode step as a chain of hipGraphs cut at the collectives: every
@@ -187,19 +202,17 @@ class _DecodeGraph:
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
         pieces: List[tuple] = []
-        cur: List[Optional[torch.cuda.CUDAGraph]] = [None]
+        cur: List[Optional[object]] = [None]
 
         def begin() -> None:
-            g = torch.cuda.CUDAGraph()
-            g.capture_begin(pool=eng.graph_pool, capture_error_mode="thread_local")
-            cur[0] = g
+            cap = self._graphs.capture(eng.rt.new_key())
+            cap.__enter__()
+            cur[0] = cap
 
         def end() -> None:
-            g, cur[0] = cur[0], None
-            g.capture_end()
-            if eng.graph_pool is None:
-                eng.graph_pool = g.pool()
-            pieces.append((g, None))
+            cap, cur[0] = cur[0], None
+            cap.__exit__(None, None, None)
+            pieces.append((cap.key, None))
 
         class _Cut:
             """Stands in for the model's communicator during the capture: ends the running
@@ -240,11 +253,11 @@ class _DecodeGraph:
                 begin()
                 self.out_tokens, self.out_lps, self.out_dec = self.run_body(eng)
                 end()
-        except BaseException:
+        except BaseException as e:
             if cur[0] is not None:          # never leave a stream capture open behind an error
                 try:
                     with torch.cuda.stream(s):
-                        cur[0].capture_end()
+                        cur[0].__exit__(type(e), e, None)
                 except Exception:  # noqa: BLE001
                     pass
             raise
@@ -323,7 +336,7 @@ class _DecodeGraph:
 
     def replay(self) -> None:
         if self.graph is not None:
-            self.graph.replay()
+            self._graphs.launch(self.graph)
             return
         if self.lists:
             from ..ops.hip import replay as replay_list
@@ -334,9 +347,9 @@ class _DecodeGraph:
                 else:
                     coll()
             return
-        for g, coll in self.pieces:
-            if g is not None:
-                g.replay()
+        for key, coll in self.pieces:
+            if key is not None:
+                self._graphs.launch(key)
             else:
                 coll()
 
@@ -356,14 +369,16 @@ class _StepStaging:
     def __init__(self, device: torch.device) -> None:
         self.device = device
         self.cap = 0
-        self.host = self.dev = None
+        self.host = self.dev = None          # numpy view of pinned memory / uint8 device tensor
         self.items: List[tuple] = []
         self.used = 0
-        self.copied: Optional[torch.cuda.Event] = None
+        self.copied: Optional[rt.Event] = None
+        self.in_flight = False
 
     def begin(self) -> None:
-        if self.copied is not None:
+        if self.in_flight:
             self.copied.synchronize()
+            self.in_flight = False
         self.items, self.used = [], 0
 
     def put(self, a: np.ndarray) -> int:
@@ -377,17 +392,29 @@ class _StepStaging:
 
     def ship(self) -> None:
         need = max(self.used, 16)
+        cuda = self.device.type == "cuda"
         if need > self.cap:
+            # grown by replacing both buffers (arenas of their own: the old ones go back whole once
+            # the tensors that view them are gone)
             self.cap = max(need * 2, 1 << 16)
-            self.host = torch.empty(self.cap, dtype=torch.uint8, pin_memory=self.device.type == "cuda")
-            self.dev = torch.empty(self.cap, dtype=torch.uint8, device=self.device)
-        hv = self.host.numpy()
+            if cuda:
+                with torch.cuda.device(rt.indexed(self.device)):
+                    self.host = rt.Arena(self.cap + 256, pinned=True).array((self.cap,), np.uint8)
+                    self.dev = rt.Arena(self.cap + 256, device=self.device).tensor((self.cap,), torch.uint8)
+                if self.copied is None:
+                    self.copied = rt.Event()
+            else:
+                self.host = np.empty(self.cap, dtype=np.uint8)
+                self.dev = torch.empty(self.cap, dtype=torch.uint8)
+        hv = self.host
         for off, a in self.items:
             hv[off:off + a.nbytes] = a.reshape(-1).view(np.uint8)
-        self.dev[:need].copy_(self.host[:need], non_blocking=True)
-        if self.device.type == "cuda":
-            self.copied = torch.cuda.Event()
+        if cuda:
+            rt.copy_async(self.dev.data_ptr(), hv.ctypes.data, need, rt.H2D)
             self.copied.record()
+            self.in_flight = True
+        else:
+            self.dev[:need].copy_(torch.from_numpy(hv[:need]))
 
     def view(self, ticket: int) -> torch.Tensor:
         off, a = self.items[ticket]
@@ -405,14 +432,23 @@ class Engine:
         cfg = model.cfg
         self.block_size = block_size
         self.max_model_len = min(max_model_len, cfg.max_position)
+        # On a GPU the engine owns a device runtime (runtime.DeviceRuntime): its step stream, the
+        # KV arena, the arenas of small device / pinned blocks and the cache of decode graphs.
+        own_stream = self.device.type == "cuda" and not serialize_streams()
+        self.rt = rt.DeviceRuntime(self.device, own_stream) if self.device.type == "cuda" else None
         if num_kv_blocks is None:
             per_block = KVCache.bytes_per_block(cfg, block_size, model.hkv)
-            if self.device.type == "cuda":
-                free, _ = torch.cuda.mem_get_info(self.device)
+            if self.rt is not None:
+                with torch.cuda.device(self.rt.device):
+                    free, _ = rt.mem_info()
                 num_kv_blocks = max(16, int(free * kv_fraction) // per_block)
             else:
                 num_kv_blocks = 256
-        self.kv = KVCache(cfg, num_kv_blocks, block_size, self.device, model.hkv)
+        kv_alloc = None
+        if self.rt is not None:
+            def kv_alloc(numel: int) -> torch.Tensor:
+                return self.rt.reserve_kv(2 * numel + 256).tensor((numel,), torch.bfloat16)
+        self.kv = KVCache(cfg, num_kv_blocks, block_size, self.device, model.hkv, alloc=kv_alloc)
         self.kvm = core.KVManager(num_kv_blocks, block_size, enable_prefix_cache)
         sc = core.SchedulerConfig()
         sc.max_batch_seqs, sc.max_prefill_tokens = max_batch_seqs, max_prefill_tokens
@@ -463,13 +499,13 @@ class Engine:
               and use_graphs_arg is not False and mode in ("lists", "graphs"))
         self.piecewise = mode if ok else ""
         self.graph_buckets = sorted(b for b in graph_buckets if b <= max_batch_seqs) or [max_batch_seqs]
-        self.graph_pool = None
         # Every engine issues its GPU work on a stream of its own, so the engines of one
         # ensemble can have steps in flight at the same time (see run_engines).
         # CONSENSUS_SERIALIZE_STREAMS=1 is the debug mode for stream-order bugs: everything runs
         # on the default stream, one engine at a time, and results must not change.
-        own_stream = self.device.type == "cuda" and not serialize_streams()
-        self.stream = torch.cuda.Stream(device=self.device) if own_stream else None
+        self.stream = self.rt.stream.torch if (self.rt is not None and self.rt.stream is not None) else None
+        self._side: Optional[rt.Stream] = None          # capture stream of the serialised debug mode
+        self._step_done = rt.Event() if self.rt is not None else None
         self._staging = _StepStaging(self.device)
         if self.stream is not None:
             self.stream.wait_stream(torch.cuda.current_stream(self.device))   # weights were written there
@@ -537,6 +573,15 @@ class Engine:
     def _on_stream(self):
         return torch.cuda.stream(self.stream) if self.stream is not None else contextlib.nullcontext()
 
+    def _capture_stream(self):
+        """The stream a decode graph is recorded on: the engine's own, or (serialised debug mode,
+        where steps run on the legacy default stream, which cannot be captured) a side stream."""
+        if self.stream is not None or self.rt is None:
+            return contextlib.nullcontext()
+        if self._side is None:
+            self._side = rt.Stream(self.rt.device)
+        return torch.cuda.stream(self._side.torch)
+
     def begin_step(self):
         """Schedules one step and enqueues its GPU work on the engine's stream without waiting
         for it. Returns an opaque token for ``end_step`` (None when idle)."""
@@ -565,8 +610,7 @@ class Engine:
                     state = self._decode_launch(plan)
             done = None
             if self.stream is not None:
-                done = torch.cuda.Event()
-                done.record(self.stream)
+                done = self._step_done.record()     # one step of an engine is in flight at a time
         return plan, state, t0, done
 
     @staticmethod
@@ -860,15 +904,14 @@ class Engine:
         # Results come back through pinned buffers: the copies are queued right behind the step,
         # and the host later waits once instead of doing three blocking reads.
         if self.device.type == "cuda":
-            g.res_tok.copy_(tok, non_blocking=True)
-            g.res_lp.copy_(lp, non_blocking=True)
+            rt.copy_async(g.res_tok.ctypes.data, tok.data_ptr(), 4 * tok.numel(), rt.D2H)
+            rt.copy_async(g.res_lp.ctypes.data, lp.data_ptr(), 4 * lp.numel(), rt.D2H)
             if any_decision:
-                g.res_dec.copy_(dl, non_blocking=True)
-            done = torch.cuda.Event()
-            done.record()
+                rt.copy_async(g.res_dec.ctypes.data, dl.data_ptr(), 4 * dl.numel(), rt.D2H)
+            done = g.done.record()
             self.metrics.inc("host.decode_launch_seconds", time.perf_counter() - t_launch)
             return g, done, any_decision
-        g.res_tok, g.res_lp, g.res_dec = tok, lp, dl
+        g.res_tok, g.res_lp, g.res_dec = tok.numpy(), lp.numpy(), dl.numpy()
         return g, None, any_decision
 
     def _decode_finish(self, plan, state) -> None:
@@ -880,14 +923,14 @@ class Engine:
             self.metrics.inc("decode.wait_seconds", time.perf_counter() - t_wait)
         t_fin = time.perf_counter()
         B = len(plan.seq_ids)
-        tok_h = g.res_tok[:B].numpy().astype(np.int32)
-        lp_h = g.res_lp[:B].numpy().astype(np.float32)
+        tok_h = g.res_tok[:B].astype(np.int32)
+        lp_h = g.res_lp[:B].astype(np.float32)
         if any_decision:
             # A chain's decision log-probs are those of its LAST step. Keeping the newest row
             # block and resolving rows only when they leave the batch avoids a Python loop
             # over every row at every step.
             cur = (np.array(plan.request_ids, copy=True), np.array(plan.seeds, copy=True),
-                   g.res_dec[:B].numpy().copy())
+                   g.res_dec[:B].copy())
             self._flush_decisions(keep=cur)
             self._last_dec = cur
         self.sched.complete_decode(plan, tok_h, lp_h)
@@ -947,6 +990,8 @@ class Engine:
             "sched.preemptions": self.sched.num_preemptions, "sched.head_skips": self.sched.num_head_skips,
             "sched.waiting": self.sched.num_waiting, "sched.running": self.sched.num_running,
         })
+        if self.rt is not None:
+            s.update(self.rt.stats())
         return s
 
 

@@ -61,13 +61,21 @@ class KVCache:
     """One flat bf16 pool: planes (layer, K|Vt) x blocks. K plane blocks are [Hkv, BS, Dh],
     Vt plane blocks are [Hkv, Dh, BS] (see attention.hip)."""
 
-    def __init__(self, cfg: ModelConfig, num_blocks: int, block_size: int, device, kv_heads: Optional[int] = None):
+    def __init__(self, cfg: ModelConfig, num_blocks: int, block_size: int, device, kv_heads: Optional[int] = None,
+                 alloc=None):
+        """``alloc(numel) -> bf16 tensor`` supplies the pool's memory (an engine on a GPU hands in
+        its runtime's KV arena); the default is a plain tensor. Either way the pool starts zeroed."""
         self.cfg, self.num_blocks, self.block_size = cfg, num_blocks, block_size
         self.kv_heads = kv_heads or cfg.num_kv_heads
         self.block_elems = self.kv_heads * block_size * cfg.head_dim
         self.n_planes = 2 * cfg.num_layers
         self.plane_elems = num_blocks * self.block_elems
-        self.pool = torch.zeros(self.n_planes * self.plane_elems, dtype=torch.bfloat16, device=device)
+        n = self.n_planes * self.plane_elems
+        if alloc is None:
+            self.pool = torch.zeros(n, dtype=torch.bfloat16, device=device)
+        else:
+            self.pool = alloc(n)
+            self.pool.zero_()
 
     def k(self, layer: int) -> torch.Tensor:
         p = self.pool[(2 * layer) * self.plane_elems:(2 * layer + 1) * self.plane_elems]

@@ -214,7 +214,9 @@ class Stream:
     ``with torch.cuda.stream(s.torch)`` makes the op layer launch on it."""
 
     def __init__(self, device: torch.device, priority: int = 0) -> None:
-        self._h = _L().lc_rt_stream_create(int(priority))
+        device = indexed(device)
+        with torch.cuda.device(device):
+            self._h = _L().lc_rt_stream_create(int(priority))
         if not self._h:
             raise DeviceRuntimeError("hipStreamCreate failed")
         self.ptr = int(_L().lc_rt_stream_handle(self._h))
@@ -311,12 +313,18 @@ class GraphCache:
             _lib.lc_rt_graphs_destroy(h)
 
 
+def indexed(device) -> torch.device:
+    """``device`` with an explicit index ("cuda" means the current device)."""
+    d = torch.device(device)
+    return d if d.index is not None else torch.device(d.type, torch.cuda.current_device())
+
+
 class DeviceRuntime:
     """Everything one engine owns on its GPU: the step stream, the KV arena, chunked arenas for
     small device and pinned blocks, and the graph cache."""
 
     def __init__(self, device: torch.device, own_stream: bool = True) -> None:
-        self.device = torch.device(device)
+        self.device = indexed(device)
         with torch.cuda.device(self.device):
             self.stream = Stream(self.device) if own_stream else None
             self.small = ChunkedArena(32 << 20, pinned=False, device=self.device)
