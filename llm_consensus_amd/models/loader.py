@@ -27,33 +27,44 @@ from .transformer import TransformerModel, hf_param_names, hf_param_shape
 class PinnedStager:
     """Host -> device copies through two pinned buffers used alternately. A buffer is reused
     only after the copy that last read it has finished (one event per buffer), so filling
-    buffer B on the CPU overlaps the DMA out of buffer A."""
+    buffer B on the CPU overlaps the DMA out of buffer A. Buffers, events and copies are the
+    device runtime's (runtime.py: pinned arenas, hipMemcpyAsync)."""
 
     def __init__(self, device) -> None:
         self.device = torch.device(device)
-        self._bufs = [None, None]
+        self._bufs = [None, None]        # numpy uint8 views of pinned arena memory
         self._events = [None, None]
+        self._busy = [False, False]
         self._turn = 0
         self.bytes_moved = 0
 
     def to_device(self, host: torch.Tensor) -> torch.Tensor:
         if self.device.type != "cuda":
             return host
+        from .. import runtime as rt
+
         host = host.contiguous()
         n = host.numel() * host.element_size()
         i = self._turn
         self._turn ^= 1
-        if self._events[i] is not None:
+        if self._busy[i]:
             self._events[i].synchronize()
-        if self._bufs[i] is None or self._bufs[i].numel() < n:
-            self._bufs[i] = torch.empty(max(n, 1 << 20), dtype=torch.uint8).pin_memory()
-        stage = self._bufs[i][:n].view(host.dtype).view(host.shape)
-        stage.copy_(host)
-        out = torch.empty(host.shape, dtype=host.dtype, device=self.device)
-        out.copy_(stage, non_blocking=True)
-        ev = torch.cuda.Event()
-        ev.record(torch.cuda.current_stream(self.device))
-        self._events[i] = ev
+            self._busy[i] = False
+        dev = rt.indexed(self.device)
+        with torch.cuda.device(dev):
+            if self._bufs[i] is None or self._bufs[i].nbytes < n:
+                cap = max(n, 1 << 20)
+                self._bufs[i] = rt.Arena(cap + 256, pinned=True).array((cap,), "uint8")
+            if self._events[i] is None:
+                self._events[i] = rt.Event()
+            stage = self._bufs[i]
+            # bf16 has no numpy dtype: move raw bytes
+            stage[:n] = host.reshape(-1).view(torch.uint8).numpy() if n else stage[:0]
+            out = torch.empty(host.shape, dtype=host.dtype, device=dev)
+            rt.copy_async(out.data_ptr(), stage.ctypes.data, n, rt.H2D,
+                          torch.cuda.current_stream(dev).cuda_stream)
+            self._events[i].record(torch.cuda.current_stream(dev).cuda_stream)
+            self._busy[i] = True
         self.bytes_moved += n
         return out
 
