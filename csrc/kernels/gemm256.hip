@@ -1,29 +1,30 @@
-// Large-M bf16 GEMM, 256(n) x 256(m) x 64(k) block tile, 8 waves, LDS-DMA staging that
-// stays in flight across barriers (counted s_waitcnt vmcnt, raw s_barrier).
+// Large-M bf16 GEMM, 256(n) x 256(m) x 64(k) block tile, 8 waves, requests that stay in flight
+// across barriers (counted s_waitcnt vmcnt, raw s_barrier).
 //
-// Same operand conventions as gemm.hip: packed weights (MFMA-fragment order) are the
-// MFMA A operand, activations the B operand, both staged with global_load_lds_dwordx4:
-// weights as ready-made fragments (lane-linear image, conflict-free ds_read_b128),
-// activations as whole 128-byte rows in an XOR-swizzled image.
+// Same operand conventions as gemm.hip: packed weights (MFMA-fragment order) are the MFMA A
+// operand, activations the B operand. Wave (wn = w&3, wm = w>>2) owns 64 n x 128 m of the tile =
+// 4 x 8 accumulator fragments (128 VGPRs). Each phase of a K-tile is
+//     R (fragment reads, requests, waits) | barrier | M (16 MFMAs) | barrier
+// and waves 4-7 run one barrier behind waves 0-3, so on every SIMD one wave is in M while its
+// partner is in R. The request queue is never drained inside the loop.
 //
-// Work split. Wave (wn = w&3, wm = w>>2) owns 64 n x 128 m of the tile = 4 x 8
-// accumulator fragments (128 VGPRs). A K-tile (64 deep) is consumed in four phases of
-// 16 MFMAs, one 2(nt) x 4(mt) quadrant each, in the order
-//     P1 (n-lo, m-lo)   P2 (n-hi, m-lo)   P3 (n-hi, m-hi)   P4 (n-lo, m-hi)
-// so all 8 weight fragments are read once in P1 and the activation fragments in two
-// halves (P1, and P2 for use in P3/P4).
-//
-// Staging. A K-tile is four 16-KiB "halves" (W0, W1, X0, X1); each wave moves one 2-KiB
-// slice of a half with two LDS-DMA instructions. One half is issued per phase, running
-// ahead of the math:
-//     P1(t): X1(t+1)   P2(t): W0(t+2)   P3(t): W1(t+2)   P4(t): X0(t+2)
-// Each phase is R (LDS reads, DMA issue, waits) | barrier | M (16 MFMAs) | barrier, and waves
-// 4-7 run one barrier behind waves 0-3, so on every SIMD one wave is in M while its partner
-// is in R. A region is re-staged only after a barrier that follows the retirement
-// (lgkmcnt(0)) of its last readers in BOTH groups (W regions are last read in P1, X regions
-// in P2). In P4's R part a wave waits with vmcnt(6): everything but the three newest halves
-// -- i.e. all of K-tile t+1 -- has landed; two barriers later the leading group reads it.
-// The LDS-DMA queue is never drained inside the loop.
+// Two main loops (SCHED):
+//   2 (default)  weights straight from global memory into registers (they are stored as fragments),
+//                one K-tile ahead; activations through three 32-KiB LDS stages filled by LDS-DMA as
+//                whole 128-byte rows in an XOR-swizzled image; phases cut by (k-step, m-half).
+//                Described at the loop.
+//   0            both operands through LDS (LC_GEMM256_SCHED=0, kept for comparison runs): a K-tile
+//                is four 16-KiB "halves" (W0, W1, X0, X1), each wave moves one 2-KiB slice of a
+//                half with two LDS-DMA instructions, one half per phase, running ahead of the math:
+//                    P1(t): X1(t+1)   P2(t): W0(t+2)   P3(t): W1(t+2)   P4(t): X0(t+2)
+//                with the phases P1 (n-lo, m-lo)  P2 (n-hi, m-lo)  P3 (n-hi, m-hi)  P4 (n-lo, m-hi),
+//                so all 8 weight fragments are read in P1 and the activation fragments in P1 and P2.
+//                A region is re-staged only after a barrier that follows the retirement
+//                (lgkmcnt(0)) of its last readers in BOTH groups; in P4's R part a wave waits with
+//                vmcnt(6): everything but the three newest halves -- i.e. all of K-tile t+1 -- has
+//                landed; two barriers later the leading group reads it.
+#include <stdlib.h>
+
 #include "gemm_common.h"
 
 namespace {
@@ -74,6 +75,22 @@ LC_DEVICE int g2_x_off(int kt, int lane) {
   return (r >> 3) * 1024 + rr * 128 + (((kt * 4 + (lane >> 4)) ^ rr) << 4);
 }
 
+// ---- SCHED 2: phases cut by (k-step, m-half), weights in registers ----
+// LDS: three X stages of 32 KiB (rows 0-127 / 128-255 of a K-tile in two 16-KiB halves); the
+// allocation is 128 KiB because the epilogue stages the output tile through it.
+constexpr int G2B_XSTAGE = 32 * 1024;
+constexpr int G2B_LDS = 128 * 1024;
+
+// 16 MFMAs of one k-step: all four n-fragments against four m-fragments.
+#define G2B_MFMA(AFR, BFR, MLO)                                                                       \
+  do {                                                                                                \
+    __builtin_amdgcn_s_setprio(1);                                                                    \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                     \
+      _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                   \
+        acc[i][(MLO) + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(AFR[i], BFR[j], acc[i][(MLO) + j], 0, 0, 0); \
+    __builtin_amdgcn_s_setprio(0);                                                                    \
+  } while (0)
+
 #define G2_MFMA_QUADRANT(NLO, BFR, MLO)                                                              \
   do {                                                                                               \
     __builtin_amdgcn_s_setprio(1);                                                                   \
@@ -96,7 +113,7 @@ LC_DEVICE int g2_x_off(int kt, int lane) {
 // offsets[e] .. offsets[e+1] and the weights at Wp + e * expert_stride. m-tiles are numbered
 // through all experts (tiles_m is an upper bound: total_rows / 256 + E); a block walks the E+1
 // offsets to find its expert and leaves if its m-tile is past the last one in use.
-template <int EPI, bool GROUPED = false>
+template <int EPI, bool GROUPED = false, int SCHED = 0>
 __global__ __launch_bounds__(512) void gemm256_kernel(const bf16_t* __restrict__ Wp,
                                                       const bf16_t* __restrict__ X, void* __restrict__ Y,
                                                       const bf16_t* __restrict__ bias, int M, int N, int K,
@@ -151,6 +168,130 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const bf16_t* __restrict__
   for (int i = 0; i < 4; ++i)
 #pragma unroll
     for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  if constexpr (SCHED == 2) {
+    // SCHED 2. A K-tile is consumed in four phases of 16 MFMAs, one k-step (32 deep) of all four
+    // n-fragments against four m-fragments each:
+    //     P1 (k0, m-lo)   P2 (k0, m-hi)   P3 (k1, m-hi)   P4 (k1, m-lo)
+    // so every accumulator still receives k0 before k1 of each K-tile (results equal SCHED 0 bit for
+    // bit) and every phase reads four activation fragments from LDS. The WEIGHT fragments never
+    // pass through LDS: the packed weights are stored as ready-made MFMA fragments, so a wave loads
+    // its own four n-fragments of both k-steps straight from global memory into registers (one
+    // coalesced KiB per instruction, two per phase), one K-tile ahead, double-buffered. LDS then
+    // carries the activations only (three 32-KiB stages; X of K-tile t+2 is requested in P1 and P3
+    // of K-tile t into the stage K-tile t-1 used): 128 KiB of fragment reads and 32 KiB of LDS-DMA
+    // writes per K-tile and CU instead of 192 + 64. That matters because the LDS traffic of one
+    // wave slows the MFMAs of its SIMD partner (profiles/README.md). Every request is issued
+    // unconditionally (indices are clamped at the end of K) so that the number of memory
+    // operations between a request and its first use is the same on every path, and all waits
+    // are counted by hand.
+    bf16x8 A0[2][4], A1[2][4], bA[4];   // one set of activation fragments: read and consumed within a phase
+    const int xoff0 = g2_x_off(0, lane), xoff1 = g2_x_off(1, lane);
+    const bf16_t* wbase = c.Wp + (static_cast<size_t>(c.nt0 + wn * 4) * c.KT + c.kt_lo * 2) * 512 + lane * 8;
+    const size_t wnt = static_cast<size_t>(c.KT) * 512;      // elements between consecutive n-tiles
+    // The register loads are issued from inline assembly and waited for with counted vmcnt like the
+    // LDS-DMA: left to the compiler, every wait for them becomes vmcnt(0), because it treats a pending
+    // global_load ... lds as a FLAT access whose return order is unknown.
+    auto wfrag = [&](int i, int kidx) -> bf16x8 {            // fragment of n-tile i, 32-deep k index kidx
+      bf16x8 v;
+      const bf16_t* ptr = wbase + i * wnt + static_cast<size_t>(kidx) * 512;
+      asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(v) : "v"(ptr) : "memory");
+      return v;
+    };
+    auto xissue = [&](int k_tile, int half, int xs) {        // X rows [128 half, +128) of K-tile k_tile
+      const int kk = k_tile < c.nk ? k_tile : c.nk - 1;
+      const int kt0 = (c.kt_lo + kk) * 2;
+      const int tile = half * 8 + wave;
+      const int rr = lane >> 3, lc = lane & 7;
+      int row0 = c.m0 + tile * 16 + rr, row1 = row0 + 8;
+      row0 = row0 < c.M ? row0 : c.M - 1;
+      row1 = row1 < c.M ? row1 : c.M - 1;
+      const int koff = kt0 * 32 + ((lc ^ rr) << 3);
+      char* dst = smem + xs * G2B_XSTAGE + (tile * 2) * 1024;
+      __builtin_amdgcn_global_load_lds(LC_GLOBAL_PTR(c.X + static_cast<size_t>(row0) * c.K + koff), LC_LDS_PTR(dst), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds(LC_GLOBAL_PTR(c.X + static_cast<size_t>(row1) * c.K + koff), LC_LDS_PTR(dst + 1024), 16, 0, 0);
+    };
+    xissue(0, 0, 0);
+    xissue(0, 1, 0);
+    xissue(1, 0, 1);
+    xissue(1, 1, 1);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      A0[0][i] = wfrag(i, 0);
+      A1[0][i] = wfrag(i, 1);
+    }
+    // Everything: the first K-tile consumes the weight fragments requested last. With X(1) in
+    // front of them, the counted waits of the loop hold from its first K-tile on.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (wave >= 4) G2_BARRIER();
+    int xs = 0;
+#define G2C_KTILE(T, CUR, NXT)                                                                          \
+    do {                                                                                                \
+      const int t_ = (T);                                                                               \
+      const char* ximg = smem + xs * G2B_XSTAGE + (wm * 8 * 2) * 1024;                                  \
+      const int xs2 = xs == 0 ? 2 : xs - 1;                                                             \
+      const int kn = (t_ + 1 < c.nk ? t_ + 1 : c.nk - 1) * 2;   /* k index of the next K-tile's fragments */ \
+      /* P1 (k0, m-lo) */                                                                               \
+      _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                     \
+        bA[j] = *reinterpret_cast<const bf16x8*>(ximg + j * 2048 + xoff0);                              \
+      A0[NXT][0] = wfrag(0, kn);                                                                        \
+      A0[NXT][1] = wfrag(1, kn);                                                                        \
+      xissue(t_ + 2, 0, xs2);                                                                           \
+      /* A0[CUR] is in: its second half was requested in P2 of the previous K-tile, ten memory */       \
+      /* operations ago (4 + 2 + 4) */                                                                  \
+      asm volatile("s_waitcnt vmcnt(10) lgkmcnt(0)" ::: "memory");                                      \
+      G2_BARRIER();                                                                                     \
+      G2B_MFMA(A0[CUR], bA, 0);                                                                         \
+      G2_BARRIER();                                                                                     \
+      /* P2 (k0, m-hi) */                                                                               \
+      _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                     \
+        bA[j] = *reinterpret_cast<const bf16x8*>(ximg + (4 + j) * 2048 + xoff0);                        \
+      A0[NXT][2] = wfrag(2, kn);                                                                        \
+      A0[NXT][3] = wfrag(3, kn);                                                                        \
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                \
+      G2_BARRIER();                                                                                     \
+      G2B_MFMA(A0[CUR], bA, 4);                                                                         \
+      G2_BARRIER();                                                                                     \
+      /* P3 (k1, m-hi) */                                                                               \
+      _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                     \
+        bA[j] = *reinterpret_cast<const bf16x8*>(ximg + (4 + j) * 2048 + xoff1);                        \
+      A1[NXT][0] = wfrag(0, kn + 1);                                                                    \
+      A1[NXT][1] = wfrag(1, kn + 1);                                                                    \
+      xissue(t_ + 2, 1, xs2);                                                                           \
+      /* A1[CUR] is in: its second half was requested in P4 of the previous K-tile (4 + 2 + 4) */       \
+      asm volatile("s_waitcnt vmcnt(10) lgkmcnt(0)" ::: "memory");                                      \
+      G2_BARRIER();                                                                                     \
+      G2B_MFMA(A1[CUR], bA, 4);                                                                         \
+      G2_BARRIER();                                                                                     \
+      /* P4 (k1, m-lo) */                                                                               \
+      _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                     \
+        bA[j] = *reinterpret_cast<const bf16x8*>(ximg + j * 2048 + xoff1);                              \
+      A1[NXT][2] = wfrag(2, kn + 1);                                                                    \
+      A1[NXT][3] = wfrag(3, kn + 1);                                                                    \
+      /* X of K-tile t+1 has landed: its second half was requested in P3 of K-tile t-1, fourteen */     \
+      /* memory operations ago (2 + 4 + 2 + 4 + 2) */                                                   \
+      asm volatile("s_waitcnt vmcnt(14) lgkmcnt(0)" ::: "memory");                                      \
+      G2_BARRIER();                                                                                     \
+      G2B_MFMA(A1[CUR], bA, 0);                                                                         \
+      G2_BARRIER();                                                                                     \
+      xs = xs == 2 ? 0 : xs + 1;                                                                        \
+    } while (0)
+    int t = 0;
+    for (; t + 1 < c.nk; t += 2) {
+      G2C_KTILE(t, 0, 1);
+      G2C_KTILE(t + 1, 1, 0);
+    }
+    if (t < c.nk) G2C_KTILE(t, 0, 1);                       // odd number of K-tiles
+#undef G2C_KTILE
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the clamped requests of the last K-tiles
+    // The last K-tile's register loads are never consumed. Their destination registers must still
+    // belong to them until the wait above: a register the compiler considered free would be handed
+    // to another value and then overwritten when the load lands. These empty statements are that
+    // claim (a "use" after the wait).
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      asm volatile("" ::"v"(A0[0][i]), "v"(A0[1][i]), "v"(A1[0][i]), "v"(A1[1][i]));
+  } else {
   bf16x8 a[4][2], b0[4][2], b1[4][2];
   const int xoff[2] = {g2_x_off(0, lane), g2_x_off(1, lane)};
 
@@ -213,6 +354,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const bf16_t* __restrict__
     G2_BARRIER();
     G2_MFMA_QUADRANT(0, b1, 4);
     G2_BARRIER();
+  }
   }
   if (wave < 4) G2_BARRIER();  // balance the stagger barrier
 
@@ -297,6 +439,13 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const bf16_t* __restrict__
 
 }  // namespace
 
+// Main-loop form: 2 = weights in registers, activations through LDS (default); LC_GEMM256_SCHED=0
+// selects the older form with both operands through LDS (kept for comparison runs).
+static int g2_sched() {
+  static const int v = getenv("LC_GEMM256_SCHED") ? atoi(getenv("LC_GEMM256_SCHED")) : 2;
+  return v;
+}
+
 // Y = X * W^T with the 256x256 pipelined tile. Requirements: K % 64 == 0, n_pad % 256 == 0.
 LC_EXPORT int lc_gemm256_splitk(const void* Wp, const void* X, void* Y, int M, int N, int K, int n_pad, int ldy,
                                 int splits, hipStream_t stream);
@@ -320,6 +469,26 @@ LC_EXPORT int lc_gemm256(const void* Wp, const void* X, void* Y, const void* bia
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256_kernel<EPI_SWIGLU>),
                         hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
   });
+  if (g2_sched() == 2) {
+    static LcDeviceOnce s2_once;
+    s2_once.run([&] {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256_kernel<EPI_BF16, false, 2>),
+                          hipFuncAttributeMaxDynamicSharedMemorySize, G2B_LDS);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256_kernel<EPI_F32, false, 2>),
+                          hipFuncAttributeMaxDynamicSharedMemorySize, G2B_LDS);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256_kernel<EPI_SWIGLU, false, 2>),
+                          hipFuncAttributeMaxDynamicSharedMemorySize, G2B_LDS);
+    });
+    if (epi == EPI_BF16)
+      gemm256_kernel<EPI_BF16, false, 2><<<grid, block, G2B_LDS, stream>>>(w, x, Y, b, M, N, K, ldy, tiles_m, tiles_n);
+    else if (epi == EPI_F32)
+      gemm256_kernel<EPI_F32, false, 2><<<grid, block, G2B_LDS, stream>>>(w, x, Y, b, M, N, K, ldy, tiles_m, tiles_n);
+    else if (epi == EPI_SWIGLU)
+      gemm256_kernel<EPI_SWIGLU, false, 2><<<grid, block, G2B_LDS, stream>>>(w, x, Y, b, M, N, K, ldy, tiles_m, tiles_n);
+    else
+      return -2;
+    LC_RETURN_LAST_ERROR();
+  }
   if (epi == EPI_BF16)
     gemm256_kernel<EPI_BF16><<<grid, block, lds, stream>>>(w, x, Y, b, M, N, K, ldy, tiles_m, tiles_n);
   else if (epi == EPI_F32)
@@ -351,6 +520,24 @@ LC_EXPORT int lc_gemm256_grouped(const void* Wp_all, long long expert_stride, co
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256_kernel<EPI_SWIGLU, true>),
                         hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
   });
+  if (g2_sched() == 2) {
+    static LcDeviceOnce s2_once;
+    s2_once.run([&] {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256_kernel<EPI_BF16, true, 2>),
+                          hipFuncAttributeMaxDynamicSharedMemorySize, G2B_LDS);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256_kernel<EPI_SWIGLU, true, 2>),
+                          hipFuncAttributeMaxDynamicSharedMemorySize, G2B_LDS);
+    });
+    if (epi == EPI_BF16)
+      gemm256_kernel<EPI_BF16, true, 2><<<grid, block, G2B_LDS, stream>>>(w, x, Y, nullptr, total_rows, N, K, ldy,
+                                                                          tiles_m, tiles_n, expert_stride, off, E);
+    else if (epi == EPI_SWIGLU)
+      gemm256_kernel<EPI_SWIGLU, true, 2><<<grid, block, G2B_LDS, stream>>>(w, x, Y, nullptr, total_rows, N, K, ldy,
+                                                                            tiles_m, tiles_n, expert_stride, off, E);
+    else
+      return -2;
+    LC_RETURN_LAST_ERROR();
+  }
   if (epi == EPI_BF16)
     gemm256_kernel<EPI_BF16, true><<<grid, block, lds, stream>>>(w, x, Y, nullptr, total_rows, N, K, ldy, tiles_m,
                                                                  tiles_n, expert_stride, off, E);
@@ -376,6 +563,17 @@ LC_EXPORT int lc_gemm256_splitk(const void* Wp, const void* X, void* Y, int M, i
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256_kernel<EPI_F32>),
                         hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
   });
+  if (g2_sched() == 2) {
+    static LcDeviceOnce s2_once;
+    s2_once.run([&] {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256_kernel<EPI_F32, false, 2>),
+                          hipFuncAttributeMaxDynamicSharedMemorySize, G2B_LDS);
+    });
+    gemm256_kernel<EPI_F32, false, 2><<<grid, block, G2B_LDS, stream>>>(
+        static_cast<const bf16_t*>(Wp), static_cast<const bf16_t*>(X), Y, nullptr, M, N, K, ldy, tiles_m, tiles_n, 0,
+        nullptr, 0, (K / G2_BK) / splits);
+    LC_RETURN_LAST_ERROR();
+  }
   gemm256_kernel<EPI_F32><<<grid, block, lds, stream>>>(static_cast<const bf16_t*>(Wp), static_cast<const bf16_t*>(X), Y,
                                                         nullptr, M, N, K, ldy, tiles_m, tiles_n, 0, nullptr, 0,
                                                         (K / G2_BK) / splits);
