@@ -11,7 +11,7 @@
 // Two main loops (SCHED):
 //   2 (default)  weights straight from global memory into registers (they are stored as fragments),
 //                one K-tile ahead; activations through three 32-KiB LDS stages filled by LDS-DMA as
-//                whole 128-byte rows in an XOR-swizzled image; phases cut by (k-step, m-half).
+//                whole 128-byte rows in an XOR-swizzled image; two phases per K-tile, one per k-step.
 //                Described at the loop.
 //   0            both operands through LDS (LC_GEMM256_SCHED=0, kept for comparison runs): a K-tile
 //                is four 16-KiB "halves" (W0, W1, X0, X1), each wave moves one 2-KiB slice of a
@@ -81,13 +81,14 @@ LC_DEVICE int g2_x_off(int kt, int lane) {
 constexpr int G2B_XSTAGE = 32 * 1024;
 constexpr int G2B_LDS = 128 * 1024;
 
-// 16 MFMAs of one k-step: all four n-fragments against four m-fragments.
-#define G2B_MFMA(AFR, BFR, MLO)                                                                       \
+// 32 MFMAs of one k-step: all four n-fragments against all eight m-fragments.
+#define G2B_MFMA32(AFR, BFR)                                                                          \
   do {                                                                                                \
     __builtin_amdgcn_s_setprio(1);                                                                    \
-    _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                     \
-      _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                   \
-        acc[i][(MLO) + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(AFR[i], BFR[j], acc[i][(MLO) + j], 0, 0, 0); \
+    _Pragma("unroll") for (int jh = 0; jh < 8; jh += 4)                                               \
+      _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                   \
+        _Pragma("unroll") for (int j = jh; j < jh + 4; ++j)                                           \
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(AFR[i], BFR[j], acc[i][j], 0, 0, 0);     \
     __builtin_amdgcn_s_setprio(0);                                                                    \
   } while (0)
 
@@ -169,28 +170,28 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const bf16_t* __restrict__
 #pragma unroll
     for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   if constexpr (SCHED == 2) {
-    // SCHED 2. A K-tile is consumed in four phases of 16 MFMAs, one k-step (32 deep) of all four
-    // n-fragments against four m-fragments each:
-    //     P1 (k0, m-lo)   P2 (k0, m-hi)   P3 (k1, m-hi)   P4 (k1, m-lo)
-    // so every accumulator still receives k0 before k1 of each K-tile (results equal SCHED 0 bit for
-    // bit) and every phase reads four activation fragments from LDS. The WEIGHT fragments never
-    // pass through LDS: the packed weights are stored as ready-made MFMA fragments, so a wave loads
-    // its own four n-fragments of both k-steps straight from global memory into registers (one
-    // coalesced KiB per instruction, two per phase), one K-tile ahead, double-buffered. LDS then
-    // carries the activations only (three 32-KiB stages; X of K-tile t+2 is requested in P1 and P3
-    // of K-tile t into the stage K-tile t-1 used): 128 KiB of fragment reads and 32 KiB of LDS-DMA
-    // writes per K-tile and CU instead of 192 + 64. That matters because the LDS traffic of one
-    // wave slows the MFMAs of its SIMD partner (profiles/README.md). Every request is issued
-    // unconditionally (indices are clamped at the end of K) so that the number of memory
-    // operations between a request and its first use is the same on every path, and all waits
-    // are counted by hand.
-    bf16x8 A0[2][4], A1[2][4], bA[4];   // one set of activation fragments: read and consumed within a phase
+    // SCHED 2. A K-tile is consumed in two phases of 32 MFMAs, one k-step (32 deep) of all four
+    // n-fragments against all eight m-fragments each (P1 = k0, P2 = k1), so every accumulator
+    // receives k0 before k1 of each K-tile (results equal SCHED 0 bit for bit), a phase reads
+    // eight activation fragments from LDS, and there are four barrier-to-barrier slots per K-tile
+    // instead of eight (each slot carries ~75 cycles of barrier and hand-over cost on top of its
+    // MFMAs). The WEIGHT fragments never pass through LDS: the packed weights are stored as
+    // ready-made MFMA fragments, so a wave loads its own four n-fragments of one k-step per phase
+    // straight from global memory into registers (one coalesced KiB per instruction), one K-tile
+    // ahead, double-buffered. LDS carries the activations only (three 32-KiB stages; the two
+    // halves of X of K-tile t+2 are requested in P1 and P2 of K-tile t into the stage K-tile t-1
+    // used): 128 KiB of fragment reads and 32 KiB of LDS-DMA writes per K-tile and CU instead of
+    // 192 + 64. That matters because the LDS traffic of one wave slows the MFMAs of its SIMD
+    // partner (profiles/README.md). Every request is issued unconditionally (indices are clamped
+    // at the end of K) so that the number of memory operations between a request and its first
+    // use is the same on every path, and all waits are counted by hand: left to the compiler,
+    // every wait for a register load becomes vmcnt(0), because it treats a pending
+    // global_load ... lds as a FLAT access whose return order is unknown.
+    bf16x8 A0[2][4], A1[2][4], bX[8];
     const int xoff0 = g2_x_off(0, lane), xoff1 = g2_x_off(1, lane);
     const bf16_t* wbase = c.Wp + (static_cast<size_t>(c.nt0 + wn * 4) * c.KT + c.kt_lo * 2) * 512 + lane * 8;
     const size_t wnt = static_cast<size_t>(c.KT) * 512;      // elements between consecutive n-tiles
-    // The register loads are issued from inline assembly and waited for with counted vmcnt like the
-    // LDS-DMA: left to the compiler, every wait for them becomes vmcnt(0), because it treats a pending
-    // global_load ... lds as a FLAT access whose return order is unknown.
+    // register loads from inline assembly: the compiler neither waits for them nor moves them
     auto wfrag = [&](int i, int kidx) -> bf16x8 {            // fragment of n-tile i, 32-deep k index kidx
       bf16x8 v;
       const bf16_t* ptr = wbase + i * wnt + static_cast<size_t>(kidx) * 512;
@@ -230,49 +231,27 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const bf16_t* __restrict__
       const int t_ = (T);                                                                               \
       const char* ximg = smem + xs * G2B_XSTAGE + (wm * 8 * 2) * 1024;                                  \
       const int xs2 = xs == 0 ? 2 : xs - 1;                                                             \
-      const int kn = (t_ + 1 < c.nk ? t_ + 1 : c.nk - 1) * 2;   /* k index of the next K-tile's fragments */ \
-      /* P1 (k0, m-lo) */                                                                               \
-      _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                     \
-        bA[j] = *reinterpret_cast<const bf16x8*>(ximg + j * 2048 + xoff0);                              \
-      A0[NXT][0] = wfrag(0, kn);                                                                        \
-      A0[NXT][1] = wfrag(1, kn);                                                                        \
+      const int kn = (t_ + 1 < c.nk ? t_ + 1 : c.nk - 1) * 2;                                           \
+      /* P1 (k0, all m) */                                                                              \
+      _Pragma("unroll") for (int j = 0; j < 8; ++j)                                                     \
+        bX[j] = *reinterpret_cast<const bf16x8*>(ximg + j * 2048 + xoff0);                              \
+      _Pragma("unroll") for (int i = 0; i < 4; ++i) A0[NXT][i] = wfrag(i, kn);                          \
       xissue(t_ + 2, 0, xs2);                                                                           \
-      /* A0[CUR] is in: its second half was requested in P2 of the previous K-tile, ten memory */       \
-      /* operations ago (4 + 2 + 4) */                                                                  \
-      asm volatile("s_waitcnt vmcnt(10) lgkmcnt(0)" ::: "memory");                                      \
-      G2_BARRIER();                                                                                     \
-      G2B_MFMA(A0[CUR], bA, 0);                                                                         \
-      G2_BARRIER();                                                                                     \
-      /* P2 (k0, m-hi) */                                                                               \
-      _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                     \
-        bA[j] = *reinterpret_cast<const bf16x8*>(ximg + (4 + j) * 2048 + xoff0);                        \
-      A0[NXT][2] = wfrag(2, kn);                                                                        \
-      A0[NXT][3] = wfrag(3, kn);                                                                        \
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                \
-      G2_BARRIER();                                                                                     \
-      G2B_MFMA(A0[CUR], bA, 4);                                                                         \
-      G2_BARRIER();                                                                                     \
-      /* P3 (k1, m-hi) */                                                                               \
-      _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                     \
-        bA[j] = *reinterpret_cast<const bf16x8*>(ximg + (4 + j) * 2048 + xoff1);                        \
-      A1[NXT][0] = wfrag(0, kn + 1);                                                                    \
-      A1[NXT][1] = wfrag(1, kn + 1);                                                                    \
-      xissue(t_ + 2, 1, xs2);                                                                           \
-      /* A1[CUR] is in: its second half was requested in P4 of the previous K-tile (4 + 2 + 4) */       \
-      asm volatile("s_waitcnt vmcnt(10) lgkmcnt(0)" ::: "memory");                                      \
-      G2_BARRIER();                                                                                     \
-      G2B_MFMA(A1[CUR], bA, 4);                                                                         \
-      G2_BARRIER();                                                                                     \
-      /* P4 (k1, m-lo) */                                                                               \
-      _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                     \
-        bA[j] = *reinterpret_cast<const bf16x8*>(ximg + j * 2048 + xoff1);                              \
-      A1[NXT][2] = wfrag(2, kn + 1);                                                                    \
-      A1[NXT][3] = wfrag(3, kn + 1);                                                                    \
-      /* X of K-tile t+1 has landed: its second half was requested in P3 of K-tile t-1, fourteen */     \
-      /* memory operations ago (2 + 4 + 2 + 4 + 2) */                                                   \
+      /* A0[CUR]: requested at the start of P1 of K-tile t-1, 2 + 6 + 6 = 14 operations ago */          \
       asm volatile("s_waitcnt vmcnt(14) lgkmcnt(0)" ::: "memory");                                      \
       G2_BARRIER();                                                                                     \
-      G2B_MFMA(A1[CUR], bA, 0);                                                                         \
+      G2B_MFMA32(A0[CUR], bX);                                                                          \
+      G2_BARRIER();                                                                                     \
+      /* P2 (k1, all m) */                                                                              \
+      _Pragma("unroll") for (int j = 0; j < 8; ++j)                                                     \
+        bX[j] = *reinterpret_cast<const bf16x8*>(ximg + j * 2048 + xoff1);                              \
+      _Pragma("unroll") for (int i = 0; i < 4; ++i) A1[NXT][i] = wfrag(i, kn + 1);                      \
+      xissue(t_ + 2, 1, xs2);                                                                           \
+      /* X(t+1): second half requested in P2 of K-tile t-1: 4 + 6 + 4 = 14 operations ago (the  */      \
+      /* two requests above included); A1[CUR]: requested in P2 of K-tile t-1 as well            */      \
+      asm volatile("s_waitcnt vmcnt(12) lgkmcnt(0)" ::: "memory");                                      \
+      G2_BARRIER();                                                                                     \
+      G2B_MFMA32(A1[CUR], bX);                                                                          \
       G2_BARRIER();                                                                                     \
       xs = xs == 2 ? 0 : xs + 1;                                                                        \
     } while (0)

@@ -40,7 +40,7 @@ from dataclasses import dataclass, field
 from http.server import BaseHTTPRequestHandler, ThreadingHTTPServer
 from typing import Any, Dict, List, Optional
 
-from ..consensus.backend import BackendError, GenParams
+from ..consensus.backend import BackendError, BackendStepper, GenParams
 from ..utils.log import get_logger
 
 log = get_logger("consensus.serve")
@@ -152,7 +152,17 @@ class ConsensusServer:
     def _drive_continuous(self) -> None:
         """New questions join the sessions in flight at the next engine step; every request is
         answered as soon as its own session (or generation) is done."""
-        pool = self.ensemble.strategy.pool()
+        # ONE stepper for every backend of the ensemble, shared with the pool: an engine must never
+        # be stepped from two drivers (a step the pool's driver has in flight would be followed by
+        # a second schedule() from a direct poll before its results were applied).
+        stepper = BackendStepper(list({id(b): b for b in self.ensemble.backends.values()}.values()))
+
+        def new_pool():
+            p = self.ensemble.strategy.pool()
+            p.stepper = stepper
+            return p
+
+        pool = new_pool()
         tickets: Dict[int, _Job] = {}
         direct: List[tuple] = []
         while not self._stop.is_set():
@@ -182,14 +192,13 @@ class ConsensusServer:
                     j.error = f"{type(e).__name__}: {e}"
                     self._finish(j)
             try:
+                was_active = pool.active
                 finished = pool.pump()
-                # The pool steps its members' backends while it has questions; everything else
-                # with queued direct requests (an embedder, or any backend when the pool is idle)
-                # is stepped here.
-                stepped = {id(b) for b in pool.backends} if pool.active else set()
-                for be in {id(b): b for b in self.ensemble.backends.values()}.values():
-                    if id(be) not in stepped and be.engines():
-                        be.poll()
+                # The pool advances the shared stepper while it has questions; when it is idle the
+                # direct requests are advanced here, through the same stepper.
+                if not was_active and direct:
+                    if not stepper.step():
+                        time.sleep(20e-6)
             except Exception as e:  # noqa: BLE001  never let the driver die with waiters parked on it
                 log.error("engine step failed: %s", e)
                 for j in list(tickets.values()) + [j for _, j in direct]:
@@ -197,7 +206,7 @@ class ConsensusServer:
                     self._finish(j)
                 tickets.clear()
                 direct.clear()
-                pool = self.ensemble.strategy.pool()
+                pool = new_pool()
                 continue
             for t, res in finished:
                 j = tickets.pop(t)

@@ -60,3 +60,34 @@ def test_batched_mode_is_still_available(server):
     batched = ConsensusServer(ens, port=0, continuous=False)
     assert not batched._continuous_ok()
     batched.httpd.server_close()
+
+
+def test_direct_completion_outliving_the_vote_questions_is_stepped_by_one_driver():
+    """A direct completion that is still generating when the last consensus question has been
+    answered: the engine it shares with the vote members must go on being stepped by the SAME
+    driver (a second driver would schedule a new step while the first one's step was still in
+    flight, and the engine's bookkeeping would fall apart with a KeyError)."""
+    cfg = config_from_dict({"strategy": "majority_vote", "decision_mode": "logprob", "seed": 3,
+                            "sampling": {"temperature": 0.7, "max_new_tokens": 3},
+                            "models": {"default": {"preset": "tiny-llama", "seed": 1}}})
+    ens = build_ensemble(cfg)
+    srv = ConsensusServer(ens, port=0, max_batch=8).start()
+    out = {}
+    try:
+        def ask(i):
+            out[i] = _post(srv.port, "/v1/chat/completions",
+                           {"messages": [{"role": "user", "content": f"question {i}: A. x B. y C. z D. w"}]})
+
+        def complete():
+            out["direct"] = _post(srv.port, "/v1/completions", {"model": "default", "prompt": "hello", "max_tokens": 48})
+
+        for rep in range(3):
+            ts = [threading.Thread(target=complete)] + [threading.Thread(target=ask, args=(10 * rep + i,)) for i in range(3)]
+            [t.start() for t in ts]
+            [t.join() for t in ts]
+            assert out["direct"][0] == 200 and out["direct"][1]["usage"]["completion_tokens"] == 48
+            for i in range(3):
+                st, body = out[10 * rep + i]
+                assert st == 200 and body["usage"]["total_tokens"] > 0, body
+    finally:
+        srv.shutdown()

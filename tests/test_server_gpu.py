@@ -40,7 +40,7 @@ def test_server_answers_staggered_questions_on_the_gpu(strategy):
 
         def complete():
             time.sleep(0.02)
-            out["direct"] = _post(srv.port, "/v1/completions", {"model": "a", "prompt": "hello", "max_tokens": 3})
+            out["direct"] = _post(srv.port, "/v1/completions", {"model": "a", "prompt": "hello", "max_tokens": 40})
 
         ts = [threading.Thread(target=ask, args=(i, 0.01 * i)) for i in range(6)] + [threading.Thread(target=complete)]
         [t.start() for t in ts]
