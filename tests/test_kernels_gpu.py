@@ -59,11 +59,13 @@ def test_gemm_tile(M, N, K, bias):
     assert rel_err(y32, want) < 1e-4
 
 
-@pytest.mark.parametrize("M,N,K", [(256, 256, 64), (512, 512, 128), (700, 256, 4096), (1000, 1024, 896), (257, 768, 1024)])
+@pytest.mark.parametrize("M,N,K", [(256, 256, 64), (512, 512, 128), (700, 256, 4096), (1000, 1024, 896), (257, 768, 1024),
+                                   (512, 512, 320), (300, 256, 192)])
 @pytest.mark.parametrize("mode", ["bf16", "f32_bias", "swiglu"])
 def test_gemm256_pipelined(M, N, K, mode):
-    """256x256 LDS-DMA pipelined kernel; K from 1 to 64 K-tiles exercises prologue, steady
-    state and drain; run twice to catch a race that only shows on warm caches."""
+    """256x256 pipelined kernel; K from 1 to 64 K-tiles (even and odd counts: the main loop is
+    unrolled by two K-tiles) exercises prologue, steady state and drain; run three times to catch a
+    race that only shows on warm caches."""
     X = bf(rand(M, K, scale=0.5) + torch.arange(M)[:, None] * 1e-3)
     old = ops.GEMM256_MIN_TILES, ops.WS_MAX_M
     ops.GEMM256_MIN_TILES, ops.WS_MAX_M = 0, 0
