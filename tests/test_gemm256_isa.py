@@ -1,0 +1,90 @@
+"""Build-time check of the 256x256 GEMM's main loop (csrc/kernels/gemm256.hip, SCHED 2).
+
+The loop loads its weight fragments with inline-assembly ``global_load_dwordx4`` and waits for them
+with hand-counted ``s_waitcnt vmcnt(N)``. That is only sound if, between a load and the MFMAs that
+consume it, nothing else touches the destination registers and no memory instruction the counts do
+not know about is issued: a register copy made before the data has landed would copy stale bits, a
+spill (scratch store / load) would shift every count. The compiler gives no such guarantee, so the
+generated code is inspected: hipcc cross-compiles gfx950 without a GPU."""
+import re
+import shutil
+import subprocess
+from pathlib import Path
+
+import pytest
+
+ROOT = Path(__file__).resolve().parents[1]
+HIPCC = "/opt/rocm/bin/hipcc"
+
+
+def _regs(tok):
+    m = re.fullmatch(r"v\[(\d+):(\d+)\]", tok)
+    if m:
+        return set(range(int(m.group(1)), int(m.group(2)) + 1))
+    m = re.fullmatch(r"v(\d+)", tok)
+    return {int(m.group(1))} if m else set()
+
+
+@pytest.mark.skipif(not shutil.which(HIPCC), reason="hipcc not installed")
+def test_weights_in_registers_loop_has_no_copies_spills_or_uncounted_memory_ops(tmp_path):
+    out = tmp_path / "gemm256.s"
+    subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-math-errno", "-ffp-contract=fast",
+                    "-fno-gpu-rdc", f"-I{ROOT / 'csrc' / 'kernels'}", "--cuda-device-only", "-S",
+                    str(ROOT / "csrc" / "kernels" / "gemm256.hip"), "-o", str(out)], check=True, timeout=600)
+    text = out.read_text()
+    kernels = re.findall(r"^(_ZN\S*gemm256_kernelILi\dELb[01]ELi2EE[^:\s]*):[^\n]*\n(.*?)^\.Lfunc_end", text, re.S | re.M)
+    assert len(kernels) >= 5, "expected the SCHED 2 instantiations (3 epilogues + 2 grouped)"
+    for name, body in kernels:
+        raw = [l.strip() for l in body.splitlines() if l.strip() and not l.strip().startswith(";")]
+        assert not any(l.startswith("scratch_") for l in raw), f"{name}: register spills"
+        # the steady-state loop: from a label to the backward branch that targets it, 128 MFMAs inside
+        # (two K-tiles of 64)
+        loop = None
+        for i, l in enumerate(raw):
+            m = re.match(r"(\.LBB\d+_\d+):", l)
+            if not m:
+                continue
+            for j in range(i + 1, len(raw)):
+                if re.match(r"\.LBB\d+_\d+:", raw[j]):
+                    break
+                if raw[j].startswith("s_cbranch") and raw[j].split()[-1] == m.group(1):
+                    body_ij = raw[i + 1: j]
+                    if sum(x.startswith("v_mfma") for x in body_ij) == 128:
+                        loop = body_ij
+                    break
+            if loop:
+                break
+        assert loop is not None, f"{name}: steady-state loop of 128 MFMAs not found"
+        loaded = set()
+        for l in loop:
+            if l.startswith("global_load_dwordx4"):
+                loaded |= _regs(l.split()[1].rstrip(","))
+        assert len(loaded) == 64, f"{name}: expected 16 weight fragments x 4 registers, found {len(loaded)}"
+        # a register with a load in flight belongs to that load until an MFMA has read it: going
+        # round the loop from each load, the next instruction that names the register is an MFMA
+        # (a temporary living there between the MFMA and the next load is fine)
+        touched = []
+        for l in loop:
+            op, *rest = l.replace(",", " ").split()
+            t = set()
+            for tok in rest:
+                t |= _regs(tok)
+            touched.append((op, t))
+        n = len(loop)
+        for i, (op, t) in enumerate(touched):
+            if op != "global_load_dwordx4":
+                continue
+            dst = _regs(loop[i].split()[1].rstrip(","))
+            for r in dst:
+                for k in range(1, n + 1):
+                    op2, t2 = touched[(i + k) % n]
+                    if r in t2:
+                        assert op2.startswith("v_mfma"), (
+                            f"{name}: v{r} is loaded by `{loop[i]}` and next touched by `{loop[(i + k) % n]}`")
+                        break
+        # memory operations of the loop: only the counted ones, and only the hand-written waits
+        vmem = [l.split()[0] for l in loop if l.startswith(("global_", "buffer_", "flat_", "scratch_"))]
+        assert set(vmem) <= {"global_load_dwordx4", "global_load_lds_dwordx4"}, (name, set(vmem))
+        assert vmem.count("global_load_dwordx4") == 16 and vmem.count("global_load_lds_dwordx4") == 8, name
+        waits = [l for l in loop if l.startswith("s_waitcnt") and "vmcnt" in l]
+        assert len(waits) == 4 and all(re.search(r"vmcnt\((12|14)\)", w) for w in waits), (name, waits)
