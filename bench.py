@@ -94,9 +94,9 @@ def parse_args(argv=None):
     ap.add_argument("--out", default=None, help="also write the JSON line to this file")
     ap.add_argument("--skip-spread", action="store_true",
                     help="multi-GPU runs: skip the extra run of workload A with one model per GPU")
-    ap.add_argument("--section-timeout", type=float, default=420.0,
+    ap.add_argument("--section-timeout", type=float, default=300.0,
                     help="multi-GPU runs: seconds a sharded workload (D, E) may take before it is abandoned")
-    ap.add_argument("--isolated-budget", type=float, default=1200.0,
+    ap.add_argument("--isolated-budget", type=float, default=720.0,
                     help="multi-GPU runs: seconds all child-process sections together may take; what is left "
                          "bounds each attempt, and a section that finds less than a minute left is skipped")
     ap.add_argument("--share-gpu", action="store_true",
