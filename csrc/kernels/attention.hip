@@ -386,15 +386,13 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_lds_kernel(
 // 0..G-1 carry the G query heads of this kv head. Keys [kv_begin[b], ctx_len[b]) are cut
 // into `nsplit` ranges. With partials == nullptr (nsplit == 1) the bf16 output is final.
 template <int DH>
-__global__ __launch_bounds__(64) void attn_decode_kernel(const bf16_t* __restrict__ Q, int q_stride,
-                                   const bf16_t* __restrict__ Kc, const bf16_t* __restrict__ Vt,
-                                   const int32_t* __restrict__ block_tables, int max_blocks,
-                                   const int32_t* __restrict__ ctx_lens, const int32_t* __restrict__ kv_begin,
-                                   bf16_t* __restrict__ out, float* __restrict__ part_o,
-                                   float* __restrict__ part_lse, int np_total, int Hq, int Hkv, int lbs,
-                                   float scale2, int window) {
-  const int kvh = blockIdx.x, b = blockIdx.y, split = blockIdx.z, nsplit = gridDim.z;
-  const int lane = threadIdx.x & 63;
+LC_DEVICE void decode_one_wave(const bf16_t* __restrict__ Q, int q_stride, const bf16_t* __restrict__ Kc,
+                               const bf16_t* __restrict__ Vt, const int32_t* __restrict__ block_tables,
+                               int max_blocks, const int32_t* __restrict__ ctx_lens,
+                               const int32_t* __restrict__ kv_begin, bf16_t* __restrict__ out,
+                               float* __restrict__ part_o, float* __restrict__ part_lse, int np_total, int Hq,
+                               int Hkv, int lbs, float scale2, int window, int kvh, int b, int split, int nsplit,
+                               int lane) {
   const int G = Hq / Hkv;
   const int q = lane & 31;
   const bool valid = q < G;
@@ -426,6 +424,19 @@ __global__ __launch_bounds__(64) void attn_decode_kernel(const bf16_t* __restric
     finish_and_store<DH>(st, valid ? out + static_cast<size_t>(b) * (Hq * DH) + head * DH : nullptr, nullptr,
                          nullptr, lane);
   }
+}
+
+template <int DH>
+__global__ __launch_bounds__(64) void attn_decode_kernel(const bf16_t* __restrict__ Q, int q_stride,
+                                   const bf16_t* __restrict__ Kc, const bf16_t* __restrict__ Vt,
+                                   const int32_t* __restrict__ block_tables, int max_blocks,
+                                   const int32_t* __restrict__ ctx_lens, const int32_t* __restrict__ kv_begin,
+                                   bf16_t* __restrict__ out, float* __restrict__ part_o,
+                                   float* __restrict__ part_lse, int np_total, int Hq, int Hkv, int lbs,
+                                   float scale2, int window) {
+  decode_one_wave<DH>(Q, q_stride, Kc, Vt, block_tables, max_blocks, ctx_lens, kv_begin, out, part_o, part_lse,
+                      np_total, Hq, Hkv, lbs, scale2, window, blockIdx.x, blockIdx.y, blockIdx.z, gridDim.z,
+                      threadIdx.x & 63);
 }
 
 // Multi-wave variant: the block's key range is cut into NW sub-ranges, one per wave, and the
@@ -556,25 +567,23 @@ __global__ __launch_bounds__(64) void attn_prefix_kernel(const bf16_t* __restric
 // pieces of a 512-key prompt the slots, written here and read again by the merge kernel, were
 // more traffic than the prefix keys themselves).
 template <int DH, int NW>
-__global__ __launch_bounds__(64 * NW) void attn_prefix_mw_kernel(
+LC_DEVICE void prefix_multi_wave(
     const bf16_t* __restrict__ Q, int q_stride, const bf16_t* __restrict__ Kc, const bf16_t* __restrict__ Vt,
     const int32_t* __restrict__ block_tables, int max_blocks, const int32_t* __restrict__ group_first,
     const int32_t* __restrict__ group_count, const int32_t* __restrict__ group_shared_blocks, int nsplit,
     float* __restrict__ part_o, float* __restrict__ part_lse, int np_total, int slot0, int Hq, int Hkv, int lbs,
-    float scale2) {
-  extern __shared__ __attribute__((aligned(16))) char pm_smem[];
-  float(*sm_o)[32][DH] = reinterpret_cast<float(*)[32][DH]>(pm_smem);
-  float(*sm_m)[32] = reinterpret_cast<float(*)[32]>(pm_smem + sizeof(float) * NW * 32 * DH);
-  float(*sm_l)[32] = sm_m + NW;
-  const int bx = blockIdx.x, kvh = blockIdx.y;
-  const int grp = blockIdx.z / nsplit, split = blockIdx.z % nsplit;
+    float scale2, char* pm_smem, int bx, int kvh, int bz) {
+  static_assert(NW == 4, "the merge below is a two-level tree over four waves");
+  constexpr int NV = DH / 2;                       // accumulator values per lane
+  float* sm = reinterpret_cast<float*>(pm_smem);   // [2 slots][NV + 2 values][64 lanes]
+  const int grp = bz / nsplit, split = bz % nsplit;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int G = Hq / Hkv;
   const int first = group_first[grp], count = group_count[grp];
   const int plen = group_shared_blocks[grp] << lbs;
   if (bx * 32 >= count * G) return;     // block-uniform: an empty group slot
-  const int q = lane & 31, hh = lane >> 5;
+  const int q = lane & 31;
   const int row = bx * 32 + q;
   const bool valid = row < count * G;
   const int b = first + row / G;
@@ -591,36 +600,57 @@ __global__ __launch_bounds__(64 * NW) void attn_prefix_mw_kernel(
   init_state<DH>(st);
   if (lo < hi) attend_range<DH>(st, qf, c, lo, hi, valid ? lo : 0, valid ? hi : 0, lane);
 
-  const float l_all = st.l + __shfl_xor(st.l, 32, 64);
-  if (hh == 0) {
-    sm_m[wave][q] = st.m;
-    sm_l[wave][q] = l_all;
-  }
+  // Merge of the four waves' states by log-sum-exp, as a tree: a lane of one wave and the same
+  // lane of another hold the same (row, dims) positions, so a state is handed over lane to lane
+  // through LDS (lane-major: no bank conflicts) without looking at its layout. Waves 2, 3 ->
+  // waves 0, 1; wave 1 -> wave 0, which normalises and writes the partial slot. Two states of
+  // 16.5 KiB in LDS (the all-to-all form needed four in row-major order, 65 KiB, which kept the
+  // workgroups of a launch at two per CU).
+  auto put = [&](int s_) {
+    float* p = sm + s_ * (NV + 2) * 64 + lane;
 #pragma unroll
-  for (int blk = 0; blk < DH / 32; ++blk)
+    for (int blk = 0; blk < DH / 32; ++blk)
 #pragma unroll
-    for (int g4 = 0; g4 < 4; ++g4)
-      *reinterpret_cast<f32x4*>(&sm_o[wave][q][blk * 32 + 8 * g4 + 4 * hh]) =
-          f32x4{st.o[blk][4 * g4 + 0], st.o[blk][4 * g4 + 1], st.o[blk][4 * g4 + 2], st.o[blk][4 * g4 + 3]};
+      for (int g = 0; g < 16; ++g) p[(blk * 16 + g) * 64] = st.o[blk][g];
+    p[NV * 64] = st.m;
+    p[(NV + 1) * 64] = st.l;
+  };
+  auto take = [&](int s_) {
+    const float* p = sm + s_ * (NV + 2) * 64 + lane;
+    const float m2 = p[NV * 64], l2 = p[(NV + 1) * 64];
+    const float mx = fmaxf(st.m, m2);
+    const float a1 = exp2f(st.m - mx), a2 = exp2f(m2 - mx);
+    st.l = st.l * a1 + l2 * a2;
+#pragma unroll
+    for (int blk = 0; blk < DH / 32; ++blk)
+#pragma unroll
+      for (int g = 0; g < 16; ++g) st.o[blk][g] = st.o[blk][g] * a1 + p[(blk * 16 + g) * 64] * a2;
+    st.m = mx;
+  };
+  if (wave >= 2) put(wave - 2);
   __syncthreads();
-  for (int e = threadIdx.x; e < 32 * DH; e += 64 * NW) {
-    const int qq = e / DH, d = e % DH;
-    const int r2 = bx * 32 + qq;
-    if (r2 >= count * G) continue;
-    float mx = kNegBig;
-#pragma unroll
-    for (int w = 0; w < NW; ++w) mx = fmaxf(mx, sm_m[w][qq]);
-    float num = 0.f, den = 0.f;
-#pragma unroll
-    for (int w = 0; w < NW; ++w) {
-      const float sc = exp2f(sm_m[w][qq] - mx);
-      num += sc * sm_o[w][qq][d];
-      den += sc * sm_l[w][qq];
-    }
-    const size_t slot = (static_cast<size_t>(first + r2 / G) * Hq + kvh * G + r2 % G) * np_total + slot0 + split;
-    part_o[slot * DH + d] = den > 0.f ? num / den : 0.f;
-    if (d == 0) part_lse[slot] = den > 0.f ? mx + log2f(den) : kNegBig;
+  if (wave < 2) take(wave);
+  __syncthreads();
+  if (wave == 1) put(0);
+  __syncthreads();
+  if (wave == 0) {
+    take(0);
+    const size_t slot = valid ? (static_cast<size_t>(b) * Hq + head) * np_total + slot0 + split : 0;
+    finish_and_store<DH>(st, nullptr, valid ? part_o + slot * DH : nullptr, valid ? part_lse + slot : nullptr, lane);
   }
+}
+
+template <int DH, int NW>
+__global__ __launch_bounds__(64 * NW) void attn_prefix_mw_kernel(
+    const bf16_t* __restrict__ Q, int q_stride, const bf16_t* __restrict__ Kc, const bf16_t* __restrict__ Vt,
+    const int32_t* __restrict__ block_tables, int max_blocks, const int32_t* __restrict__ group_first,
+    const int32_t* __restrict__ group_count, const int32_t* __restrict__ group_shared_blocks, int nsplit,
+    float* __restrict__ part_o, float* __restrict__ part_lse, int np_total, int slot0, int Hq, int Hkv, int lbs,
+    float scale2) {
+  extern __shared__ __attribute__((aligned(16))) char pm_smem[];
+  prefix_multi_wave<DH, NW>(Q, q_stride, Kc, Vt, block_tables, max_blocks, group_first, group_count,
+                            group_shared_blocks, nsplit, part_o, part_lse, np_total, slot0, Hq, Hkv, lbs, scale2,
+                            pm_smem, blockIdx.x, blockIdx.y, blockIdx.z);
 }
 
 // ------------------------------------------------------------------ merge
@@ -746,12 +776,7 @@ LC_EXPORT int lc_attn_prefix(const void* Q, int q_stride, const void* Kc, const 
       static_cast<const int32_t*>(group_count), static_cast<const int32_t*>(group_shared_blocks), nsplit, \
       static_cast<float*>(part_o), static_cast<float*>(part_lse), np_total, slot0, Hq, Hkv, lbs, scale2
   if (waves == 4) {
-    const size_t lds = sizeof(float) * 4 * 32 * (Dh + 2);
-    static LcDeviceOnce attr_once;
-    attr_once.run([&] {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_prefix_mw_kernel<128, 4>),
-                          hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(sizeof(float) * 4 * 32 * 130));
-    });
+    const size_t lds = sizeof(float) * 2 * (Dh / 2 + 2) * 64;
     if (Dh == 128) attn_prefix_mw_kernel<128, 4><<<grid, dim3(256), lds, stream>>>(LC_ARGS);
     else attn_prefix_mw_kernel<64, 4><<<grid, dim3(256), lds, stream>>>(LC_ARGS);
   } else if (Dh == 128) {
