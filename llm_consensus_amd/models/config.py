@@ -101,6 +101,8 @@ PRESETS: Dict[str, ModelConfig] = {
                                 model_type="mistral"),
     "tiny-mixtral": ModelConfig("tiny-mixtral", 512, 128, 2, 4, 2, 64, 256, 1e-5, 1e4, False, False, 0, 1024,
                                 4, 2, "mixtral"),
+    # four kv heads: the smallest shape a TP=4 group can shard (the judge of workload D on 4-8 ranks)
+    "tiny-judge": ModelConfig("tiny-judge", 512, 512, 2, 8, 4, 64, 512, 1e-5, 1e4, max_position=1024),
     "small-llama": ModelConfig("small-llama", 4096, 512, 4, 8, 2, 128, 1536, 1e-5, 5e5, max_position=4096),
 }
 

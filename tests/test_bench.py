@@ -124,6 +124,23 @@ def test_isolated_section_reports_which_collectives_it_used():
     assert out["moe_medoid"]["collectives"].startswith("p2p") and out["value"] == out["moe_medoid"]["value"]
 
 
+def test_four_ranks_shard_the_judge_four_ways_next_to_the_proposers():
+    """Workload D as the round-end driver starts it on a 4-GPU node (torch.distributed.run, one rank
+    per device): the judge is a TP=4 group over all four ranks, each of which also hosts a proposer.
+    `tiny-judge` is the smallest preset four ranks can shard (four kv heads)."""
+    args = [a if a != "tiny-qwen" or TINY[i - 1] != "--judge-model" else "tiny-judge" for i, a in enumerate(TINY)]
+    e = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "4",
+                        "--master-addr", "127.0.0.1", "--master-port", "29741", str(ROOT / "bench.py"), "--gpus", "4",
+                        "--workload", "D"] + args, capture_output=True, text=True, env=e, timeout=420)
+    assert p.returncode == 0, p.stderr[-3000:]
+    out = json_line(p)
+    d = out["judge_consensus"]
+    assert out["n_gpus"] == 4 and "error" not in d and d["value"] > 0 and d["judge_tp"] == 4
+    assert d["placement"]["replica0_member_gpus"]["judge"] == [0, 1, 2, 3]
+    assert sorted(g for k, v in d["placement"]["replica0_member_gpus"].items() if k != "judge" for g in v) == [0, 1, 2, 3]
+
+
 def test_three_ranks_also_report_one_model_per_gpu():
     p = run_bench(["--gpus", "3", "--workload", "A"] + TINY)
     assert p.returncode == 0, p.stderr[-3000:]
