@@ -167,3 +167,21 @@ def test_two_ranks_rehearse_every_workload_on_one_gpu():
     assert d.get("value", 0) > 0 and d["judge_tp"] == 2, d
     assert e.get("value", 0) > 0 and e["expert_parallel"] == 2 and e["ep_mode"] == "a2a", e
     assert d["collectives"].startswith("p2p") and e["collectives"].startswith("p2p")
+
+@pytest.mark.gpu
+def test_four_ranks_rehearse_the_sharded_workloads_on_one_gpu():
+    """The same with four ranks: the judge of D is a TP=4 group (`tiny-judge`: four kv heads) whose
+    ranks also host the four proposers, E is expert parallel over four ranks, and workload A runs
+    once more with one model per GPU; all through the peer-to-peer kernels."""
+    args = [x for x in TINY if x not in ("--device", "cpu")]
+    args[args.index("--judge-model") + 1] = "tiny-judge"
+    args += ["--gpus", "4", "--share-gpu", "--workload", "A,D,E"]
+    p = run_bench(args, env={"HSA_ENABLE_IPC_MODE_LEGACY": "0"}, timeout=420)
+    assert p.returncode == 0, p.stderr[-3000:]
+    out = json_line(p)
+    assert out["n_gpus"] == 4 and out["value"] > 0
+    sp, d, e = out["ensemble_one_model_per_gpu"], out["judge_consensus"], out["moe_medoid"]
+    assert sp.get("value", 0) > 0 and sp["placement"]["gpus_per_replica"] == 3, sp
+    assert d.get("value", 0) > 0 and d["judge_tp"] == 4, d
+    assert e.get("value", 0) > 0 and e["expert_parallel"] == 4 and e["ep_mode"] == "a2a", e
+    assert all(x["collectives"].startswith("p2p") for x in (sp, d, e))
