@@ -442,6 +442,7 @@ def run_replica_workloads(ctx: Ctx, out: dict) -> None:
         for key, templates, dissent in (
                 ("reference_protocol", core.PromptTemplates(), 0.0),
                 ("reference_protocol_persona_last", core.PromptTemplates.persona_last(), 0.0),
+                ("reference_protocol_persona_first", core.PromptTemplates.persona_first(), 0.0),
                 ("reference_protocol_persona_last_dissent25", core.PromptTemplates.persona_last(), 0.25)):
             panel = [Member(p, be_p, templates, gp_p, decision_mode="logprob", dissent_rate=dissent,
                             dissent_seed=1000 * ctx.rank + i) for i, p in enumerate(personas[:4])]

@@ -64,6 +64,7 @@ PYBIND11_MODULE(_core, m) {
   py::class_<PromptTemplates>(m, "PromptTemplates")
       .def(py::init(&PromptTemplates::defaults))
       .def_static("persona_last", &PromptTemplates::persona_last)
+      .def_static("persona_first", &PromptTemplates::persona_first)
       .def_readwrite("propose", &PromptTemplates::propose)
       .def_readwrite("evaluate", &PromptTemplates::evaluate)
       .def_readwrite("refine", &PromptTemplates::refine)

@@ -123,6 +123,47 @@ PromptTemplates PromptTemplates::persona_last() {
   return t;
 }
 
+PromptTemplates PromptTemplates::persona_first() {
+  PromptTemplates t = defaults();
+  const std::string head =
+      "\n---\nYour Instructions:\n"
+      "You belong to a panel of LLMs that must agree on an answer to a question. The question and "
+      "the answer, which came from the first panel member chosen, are shown at the end of these "
+      "instructions. ";
+  const std::string rules =
+      "A direct link between the answer and your domain is not required; think about indirect "
+      "or tangential links too, and about how the answer could enable, inspire or be used in "
+      "work belonging to your domain. In particular keep these aspects in mind:{tuning}\n\n";
+  const std::string tail = "\n---\nQuestion: {question}\n---\nAnswer: {answer}";
+  t.evaluate = head +
+      "Judge the answer from the point of view of your knowledge domain: {domain}. You may reply "
+      "with only one of two verdicts: Good or NeedsRefinement.\n\n" + rules +
+      "First decide whether the question has anything to do with your domain. If it does not, "
+      "you are not qualified to judge, so reply with exactly Good. If it does and you find the "
+      "answer good, reply with exactly Good. If you find the answer bad, reply with exactly "
+      "NeedsRefinement. Then, on a new line, give the reasoning behind your verdict.\n"
+      "---\nExamples:\n\n"
+      "Question: Which programming language suits a beginner?\n"
+      "Answer: Python\n"
+      "Your domain: art and imagination\n"
+      "Evaluation: Good\n"
+      "Reasoning: The question is outside your domain.\n\n"
+      "Question: What makes software simpler to update?\n"
+      "Answer: Decoupling\n"
+      "Your domain: technical rigor\n"
+      "Evaluation: NeedsRefinement\n"
+      "Reasoning: Loose coupling is only one ingredient of maintainable software and the "
+      "answer gives too little detail." + tail;
+  t.refine =
+      "\n---\nYour Instructions:\n"
+      "A user asked a question and was given an answer; both are shown at the end of these "
+      "instructions. When you evaluated that answer you said it needed refinement. Refine it as "
+      "your knowledge domain, {domain}, requires.\n\n"
+      "Let the following points guide the refinement; they need not appear in the answer "
+      "itself:{tuning}" + tail + "{reasoning}";
+  return t;
+}
+
 namespace {
 
 // Single-pass substitution so that text inserted for one placeholder is never

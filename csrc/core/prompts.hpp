@@ -40,6 +40,12 @@ struct PromptTemplates {
   // personas on one model the rules and examples are then prefilled once per answer instead
   // of N times: the shared prefix grows from roughly a quarter of the prompt to four fifths.
   static PromptTemplates persona_last();
+  // The opposite order: everything that depends on the persona, the verdict rules and the
+  // examples come FIRST, the question and the answer last. That head is the same for every
+  // question a persona ever judges, so after the first question it is served from the prefix
+  // cache (across questions of a step and across steps) and an evaluate call prefills only the
+  // question and the answer. Nothing is shared between the personas of one answer.
+  static PromptTemplates persona_first();
 };
 
 std::string render_propose(const PromptTemplates& t, const std::string& question);

@@ -97,7 +97,7 @@ class ConsensusConfig:
     sampling: SamplingConfig = field(default_factory=SamplingConfig)
     models: Dict[str, ModelSpec] = field(default_factory=lambda: {"default": ModelSpec()})
     members: List[MemberConfig] = field(default_factory=list)
-    prompt_layout: str = "reference"       # reference | persona_last (persona text at the end: longer shared prefix)
+    prompt_layout: str = "reference"       # reference | persona_last (persona text at the end: shared between the personas of an answer) | persona_first (question and answer at the end: a persona's head is cached across questions)
     prompt_propose: Optional[str] = None   # template file paths
     prompt_evaluate: Optional[str] = None
     prompt_refine: Optional[str] = None
@@ -128,7 +128,7 @@ class ConsensusConfig:
             raise ValueError(f"unknown parse_mode {self.parse_mode!r}")
         if self.decision_mode not in ("text", "logprob", "tokens"):
             raise ValueError(f"unknown decision_mode {self.decision_mode!r}")
-        if self.prompt_layout not in ("reference", "persona_last"):
+        if self.prompt_layout not in ("reference", "persona_last", "persona_first"):
             raise ValueError(f"unknown prompt_layout {self.prompt_layout!r}")
         names = [m.name for m in self.members]
         if len(set(names)) != len(names):
@@ -164,7 +164,8 @@ class ConsensusConfig:
         }[self.tie_break]
 
     def templates(self) -> "core.PromptTemplates":
-        t = core.PromptTemplates.persona_last() if self.prompt_layout == "persona_last" else core.PromptTemplates()
+        t = {"persona_last": core.PromptTemplates.persona_last,
+             "persona_first": core.PromptTemplates.persona_first}.get(self.prompt_layout, core.PromptTemplates)()
         for attr, path in (("propose", self.prompt_propose), ("evaluate", self.prompt_evaluate),
                            ("refine", self.prompt_refine)):
             if path:

@@ -51,7 +51,8 @@ def test_single_rank_line_has_every_section_and_the_contract_fields():
     assert out["n_gpus"] == 1 and out["config"]["global_batch"] == 2
     for key in ("metric", "value", "unit", "ms_per_step", "scaling", "vs_baseline", "dtype", "data", "config"):
         assert out[key] is not None, key
-    for sec in ("self_consistency", "reference_protocol", "reference_protocol_persona_last", "judge_consensus",
+    for sec in ("self_consistency", "reference_protocol", "reference_protocol_persona_last",
+                "reference_protocol_persona_first", "judge_consensus",
                 "moe_medoid"):
         assert out[sec]["value"] > 0 and out[sec]["p50_latency_ms"] > 0, sec
     assert out["judge_consensus"]["judge_tp"] == 1 and out["moe_medoid"]["expert_parallel"] == 1

@@ -43,6 +43,24 @@ def test_evaluate_prefix_is_persona_independent():
     assert len({r[len(prefix):] for r in rendered}) == len(ps)
 
 
+def test_persona_first_layout_puts_everything_question_independent_in_front():
+    """The head of a persona's evaluate prompt (instructions, domain, tuning, rules, examples) is
+    the same for every question, so a prefix cache serves it after the first one; only the
+    question and the answer follow. Same information as the reference layout."""
+    t = core.PromptTemplates.persona_first()
+    p = core.default_personas()[2]
+    a = core.render_evaluate(t, "Q one?", "A one.", p)
+    b = core.render_evaluate(t, "A much longer second question?", "Another answer.", p)
+    head = a[: a.index("\n---\nQuestion: Q one?")]
+    assert b.startswith(head) and len(head) > 0.8 * len(a)
+    assert p.domain in head and "* " in head and head.count("Evaluation:") == 2 and "NeedsRefinement" in head
+    assert a.endswith("Question: Q one?\n---\nAnswer: A one.")
+    other = core.render_evaluate(t, "Q one?", "A one.", core.default_personas()[0])
+    assert other != a and other.endswith("Question: Q one?\n---\nAnswer: A one.")
+    r = core.render_refine(t, "Q?", "A.", p, "- X: too short")
+    assert r.index(p.domain) < r.index("Question: Q?") < r.index("Answer: A.") < r.index("too short")
+
+
 def test_refine_omits_reasoning_by_default():
     t = core.PromptTemplates()
     p = core.default_personas()[0]
