@@ -80,6 +80,8 @@ def parse_args(argv=None):
     ap.add_argument("--judge-questions", type=int, default=16, help="questions per GPU per step (workload D)")
     ap.add_argument("--judge-model", default="llama-3-70b")
     ap.add_argument("--proposer-model", default="llama-3-8b")
+    ap.add_argument("--no-warm-judges", action="store_true",
+                    help="workload D: judges do not prefill the question part of their prompt during the proposer phase")
     ap.add_argument("--moe-questions", type=int, default=16, help="questions per GPU per step (workload E)")
     ap.add_argument("--moe-model", default="mixtral-8x7b")
     ap.add_argument("--moe-experts", type=int, default=8, help="experts of --moe-model (bounds the EP degree)")
@@ -678,6 +680,7 @@ def main(argv=None) -> int:
             nq = a.judge_questions * ctx.world
             cfg = W.judge_config(ctx.world, nq, a.prompt_len, a.new_tokens, samp, a.proposer_model,
                                  a.judge_model, bs=ctx.bs, prefill_tokens=a.prefill_tokens)
+            cfg.warm_judges = False if a.no_warm_judges else None      # None: when the judge's GPUs are its own
             out["judge_consensus"] = run_configured(
                 ctx, cfg, nq, a.prompt_len, a.aux_steps, aux_warm,
                 f"consensus answers/sec, 4x {a.proposer_model} proposers + {a.judge_model} judge (log-prob scoring)",

@@ -155,7 +155,11 @@ def make_members(cfg: ConsensusConfig, backends: Dict[str, Backend]) -> List[Mem
     ]
 
 
-def make_strategy(cfg: ConsensusConfig, members: List[Member], device):
+def make_strategy(cfg: ConsensusConfig, members: List[Member], device, judges_have_own_gpus: bool = False):
+    """``judges_have_own_gpus``: what ``warm_judges = None`` resolves to. Prefilling the question
+    part of the judge prompts during the proposer phase hides that work when the judges' GPUs
+    would otherwise idle; on GPUs shared with the proposers it only moves the same work
+    (measured on one MI355X: 4.46 answers/s with, 4.52 without)."""
     dev = device if str(device).startswith("cuda") else None
     voters = [m for m in members if m.role == "member"] or members
     judges = [m for m in members if m.role == "judge"]
@@ -169,7 +173,8 @@ def make_strategy(cfg: ConsensusConfig, members: List[Member], device):
                                device=dev)
     if cfg.strategy == "judge_logprob":
         return JudgeLogprob(voters, judges or voters[-1:], device=dev, micro_batches=cfg.micro_batches,
-                            min_micro_batch=cfg.min_micro_batch)
+                            min_micro_batch=cfg.min_micro_batch,
+                            warm_judges=judges_have_own_gpus if cfg.warm_judges is None else cfg.warm_judges)
     if cfg.strategy == "embedding_medoid":
         return EmbeddingMedoid(voters, (embedders or voters)[0], samples_per_member=cfg.samples_per_member, device=dev,
                                micro_batches=cfg.micro_batches, min_micro_batch=cfg.min_micro_batch)

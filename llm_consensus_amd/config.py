@@ -89,6 +89,7 @@ class ConsensusConfig:
     micro_batches: int = 2            # judge_logprob / embedding_medoid: parts of a question batch pipelined
     #                                   through the two phases (1 = propose everything, then judge everything)
     min_micro_batch: int = 32         # ... and the fewest questions such a part may hold
+    warm_judges: Optional[bool] = None  # judge_logprob: judges prefill the question part of their prompt while the proposers generate; None = when the judges have GPUs to themselves
     choices: str = "ABCD"
     tie_break: str = "lowest_class"
     deadline_s: Optional[float] = None

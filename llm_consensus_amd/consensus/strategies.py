@@ -396,10 +396,18 @@ class JudgeLogprob:
 
     def __init__(self, proposers: Sequence[Member], judges: Sequence[Member],
                  params: Optional[GenParams] = None, device=None, micro_batches: int = 2,
-                 min_micro_batch: Optional[int] = None) -> None:
+                 min_micro_batch: Optional[int] = None, warm_judges: bool = False) -> None:
         """``micro_batches`` > 1 pipelines the two phases: judges score one part of the question
         batch while the proposers generate the next (see _two_stage_pipeline); parts hold at
-        least ``min_micro_batch`` questions."""
+        least ``min_micro_batch`` questions.
+
+        ``warm_judges``: the judge's prompt starts with the question, which is known long before
+        the candidates are. When the proposals of a question are queued, so is a scoring call of
+        every judge on that leading part alone; it runs while the proposers generate (on the judge's
+        own GPUs) and leaves the question's KV blocks in the judge's prefix cache, so that scoring
+        the candidates later prefills only the candidates. Its result is not used. On GPUs the
+        judges share with the proposers it only moves the same work to an earlier time; the
+        ensemble builders switch it on when the judges' GPUs are their own."""
         if not proposers or not judges:
             raise ValueError("JudgeLogprob needs proposers and at least one judge")
         self.proposers = list(proposers)
@@ -408,11 +416,17 @@ class JudgeLogprob:
         self.device = device
         self.micro_batches = micro_batches
         self.min_micro_batch = min_micro_batch
+        self.warm_judges = warm_judges
 
     @staticmethod
     def judge_prompt(question: str, candidate: str) -> str:
         return (f"Question: {question}\nProposed answer: {candidate}\n"
                 "Is the proposed answer correct and complete? Reply Yes or No.\nVerdict:")
+
+    @staticmethod
+    def judge_prompt_head(question: str) -> str:
+        """What every judge prompt of a question starts with (see ``warm_judges``)."""
+        return f"Question: {question}\nProposed answer:"
 
     def ask_many(self, questions: Sequence[str]) -> List[ConsensusResult]:
         t0 = time.perf_counter()
@@ -420,10 +434,14 @@ class JudgeLogprob:
         prop: List[list] = [[] for _ in range(R)]
         cands: List[List[str]] = [[] for _ in range(R)]
         score_h: List[list] = [[] for _ in range(R)]
+        warm_h: List[list] = [[] for _ in range(R)]
 
         def propose(rng) -> None:
             for r in rng:
                 prop[r] = [m.submit_propose(questions[r], self.params) for m in self.proposers]
+                if self.warm_judges:
+                    warm_h[r] = [j.backend.submit_score(self.judge_prompt_head(questions[r]), self.JUDGE_TARGETS)
+                                 for j in self.judges]
 
         def judge(rng) -> None:
             for r in rng:
@@ -438,8 +456,15 @@ class JudgeLogprob:
                 score_h[r] = [[j.backend.submit_score(self.judge_prompt(questions[r], c), self.JUDGE_TARGETS)
                                for j in self.judges] for c in row]
 
-        _two_stage_pipeline(R, self.micro_batches, propose, self.proposers, judge, self.judges,
+        first = list(self.proposers) + (list(self.judges) if self.warm_judges else [])
+        _two_stage_pipeline(R, self.micro_batches, propose, first, judge, self.judges,
                             min_part=self.min_micro_batch)
+        for row in warm_h:                       # a failed warm-up costs nothing but the cache hit
+            for h in row:
+                try:
+                    h.result()
+                except BackendError:
+                    pass
         C, J = len(self.proposers), len(self.judges)
         scores = np.full((R, C, J), -1e30, dtype=np.float32)
         done_at = [t0] * R
@@ -467,7 +492,7 @@ class JudgeLogprob:
                 latency_s=(done_at[r] - t0) if done_at[r] > t0 else time.perf_counter() - t0,
                 votes=[{"candidate": self.proposers[c].name, "scores": scores[r, c].tolist()} for c in range(C)],
                 extra={"winner_score": float(red.score[r])},
-                usage=add_usage({}, list(prop[r]) + [h for row in score_h[r] for h in row]),
+                usage=add_usage({}, list(prop[r]) + [h for row in score_h[r] for h in row] + list(warm_h[r])),
             ))
         return out
 

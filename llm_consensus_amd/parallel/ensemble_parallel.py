@@ -23,7 +23,7 @@ ranks stay in step without exchanging decisions.
 """
 from __future__ import annotations
 
-from dataclasses import dataclass
+from dataclasses import dataclass, field
 from typing import Any, Dict, List, Optional, Sequence
 
 import torch
@@ -138,6 +138,7 @@ class RankLayout:
     replica_comm: Optional[Comm]
     hosted: Dict[str, Comm]              # model name -> communicator of its group (this rank is a member)
     owners: Dict[str, int]               # model name -> replica rank that publishes results
+    devices_of: Dict[str, List[int]] = field(default_factory=dict)   # model name -> ranks of its group (this rank's replica)
 
 
 def build_layout(cfg, comm: Comm, plan=None) -> RankLayout:
@@ -160,6 +161,7 @@ def build_layout(cfg, comm: Comm, plan=None) -> RankLayout:
         for name in sorted(groups):
             gc = comm.subgroup(groups[name])
             if here:
+                mine.devices_of[name] = list(groups[name])
                 mine.owners[name] = devices.index(groups[name][0])
                 if comm.rank in groups[name]:
                     mine.hosted[name] = gc if gc is not None else SingleComm()
@@ -196,7 +198,10 @@ class DistributedEnsemble:
                                                  embed_dim=model_config_of(cfg.models[name]).hidden_size,
                                                  device=self.device)
         self.members = make_members(cfg, self.backends)
-        self.strategy = make_strategy(cfg, self.members, self.device)
+        judge_gpus = {d for m in cfg.members if m.role == "judge" for d in lay.devices_of.get(cfg.models[m.model].name, [])}
+        other_gpus = {d for m in cfg.members if m.role != "judge" for d in lay.devices_of.get(cfg.models[m.model].name, [])}
+        self.strategy = make_strategy(cfg, self.members, self.device,
+                                      judges_have_own_gpus=bool(judge_gpus) and not (judge_gpus & other_gpus))
 
     def ask_many(self, questions: Sequence[str]) -> List[Any]:
         lay = self.layout

@@ -224,6 +224,8 @@ def test_tensor_parallel_judge_next_to_single_gpu_proposers():
         if "judge" in lay.hosted:
             assert lay.hosted["judge"].world == 2
             assert ens.backends["judge"].local.engine.model.tp_size == 2
+        # the judge group shares no rank with a proposer: it prefills the questions while they generate
+        assert ens.strategy.warm_judges is True
         res = ens.ask_many(QUESTIONS[:3])
         return sorted(lay.hosted), [(r.answer, r.strategy) for r in res]
 
@@ -232,6 +234,12 @@ def test_tensor_parallel_judge_next_to_single_gpu_proposers():
     assert sum("judge" in h for h in hosted) == 2 and all(len(h) == 1 for h in hosted)
     answers = [a for _, a in res]
     assert all(a == answers[0] for a in answers) and all(s == "judge_logprob" for _, s in answers[0])
+    # one process hosting everything: the warm-up would only move the same work
+    from llm_consensus_amd.app import build_ensemble
+
+    single = build_ensemble(cfg, torch.device("cpu"))
+    assert single.strategy.warm_judges is False
+    assert [(r.answer, r.strategy) for r in single.ask_many(QUESTIONS[:3])] == answers[0]
 
 
 def test_reference_protocol_runs_in_lock_step_across_ranks():

@@ -15,7 +15,7 @@ CPU = torch.device("cpu")
 QUESTIONS = [f"Question {i}: pick one. A) a B) b C) c D) d" for i in range(6)]
 
 
-def two_phase_config(strategy: str, micro_batches: int) -> ConsensusConfig:
+def two_phase_config(strategy: str, micro_batches: int, warm_judges: bool = False) -> ConsensusConfig:
     models = {"p0": ModelSpec(name="p0", preset="tiny-llama", seed=1),
               "p1": ModelSpec(name="p1", preset="tiny-qwen", seed=2),
               "second": ModelSpec(name="second", preset="tiny-mistral", seed=3)}
@@ -23,7 +23,7 @@ def two_phase_config(strategy: str, micro_batches: int) -> ConsensusConfig:
     members = [MemberConfig(name="p0", model="p0"), MemberConfig(name="p1", model="p1"),
                MemberConfig(name="second", model="second", role=role)]
     return ConsensusConfig(strategy=strategy, models=models, members=members, micro_batches=micro_batches,
-                           min_micro_batch=1,
+                           min_micro_batch=1, warm_judges=warm_judges,
                            sampling=SamplingConfig(temperature=0.0, max_new_tokens=6))
 
 
@@ -32,8 +32,8 @@ def engine_spans():
                    if e.get("cat") == "engine"), key=lambda s: s[0])
 
 
-def run_traced(strategy: str, micro_batches: int):
-    ens = build_ensemble(two_phase_config(strategy, micro_batches), CPU)
+def run_traced(strategy: str, micro_batches: int, warm_judges: bool = False):
+    ens = build_ensemble(two_phase_config(strategy, micro_batches, warm_judges), CPU)
     TRACER.clear()
     TRACER.enable(roctx=False)
     try:
@@ -73,6 +73,41 @@ def test_pipelined_schedule_overlaps_phases_and_keeps_the_answers(strategy):
     window = [(t0, t1) for t0, t1, n in p_spans if n == "second"]
     lo, hi = window[0][0], window[-1][1]
     assert sum(1 for t0, _, n in p_spans if n in ("p0", "p1") and lo < t0 < hi) >= 2
+
+
+def test_judges_prefill_the_question_while_the_proposers_generate():
+    """warm_judges: a scoring call on the leading part of the judge prompt (the question) is queued
+    with the proposals, so the judge engine works during the proposer phase even in the serial
+    schedule, the later scoring calls find the question's KV blocks in the judge's prefix cache,
+    and the answers do not change."""
+    long_q = [q + " " + "context " * 40 for q in QUESTIONS]           # several KV blocks per question
+
+    def run(warm):
+        ens = build_ensemble(two_phase_config("judge_logprob", 1, warm), CPU)
+        TRACER.clear()
+        TRACER.enable(roctx=False)
+        try:
+            res = ens.ask_many(long_q)
+            spans = engine_spans()
+        finally:
+            TRACER.disable()
+            TRACER.clear()
+        return res, spans
+
+    cold, c_spans = run(False)
+    warm, w_spans = run(True)
+    assert [r.answer for r in warm] == [r.answer for r in cold]
+    assert [r.proposer for r in warm] == [r.proposer for r in cold]
+    for a, b in zip(warm, cold):
+        assert [x for v in a.votes for x in v["scores"]] == pytest.approx([x for v in b.votes for x in v["scores"]],
+                                                                           abs=1e-3)
+
+    def judge_before_last_proposal(spans):
+        return min(t0 for t0, _, n in spans if n == "second") < max(t1 for _, t1, n in spans if n in ("p0", "p1"))
+
+    assert judge_before_last_proposal(w_spans) and not judge_before_last_proposal(c_spans)
+    # the candidates' scoring calls reuse the question's blocks: more cached prompt tokens than without
+    assert sum(r.usage["cached_tokens"] for r in warm) > sum(r.usage["cached_tokens"] for r in cold)
 
 
 def test_small_batches_are_not_cut():
