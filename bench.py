@@ -433,12 +433,14 @@ def run_replica_workloads(ctx: Ctx, out: dict) -> None:
             done = torch.tensor([[int(r.forced)] for r in results], dtype=torch.int32, device=dev)
             return int(comm.all_gather_rows(done).numel())
 
-        # Two prompt layouts: the reference's (domain named a third of the way into the evaluate
-        # prompt) and the same instructions with the persona text moved to the end, which lets the
-        # four evaluate prompts of a round share most of their prefill. Random-init weights give all
-        # four personas the same verdict, so the loop ends after one round; the third run injects
-        # seeded dissent (a Good verdict becomes NeedsRefinement with probability 0.25) to load the
-        # refinement path as well.
+        # Three prompt layouts: the reference's (question and answer first, domain named a third of
+        # the way into the evaluate prompt); the same instructions with the persona text moved to
+        # the end, which lets the four evaluate prompts of a round share most of their prefill; and
+        # with the question and the answer moved to the end, which makes a persona's whole head the
+        # same for every question (served from the prefix cache after the first). Random-init
+        # weights give all four personas the same verdict, so the loop ends after one round; the
+        # last run injects seeded dissent (a Good verdict becomes NeedsRefinement with probability
+        # 0.25) to load the refinement path as well.
         sess = core.SessionConfig()
         sess.max_rounds, sess.seed = 5, 4242 + ctx.rank
         for key, templates, dissent in (
