@@ -2,8 +2,8 @@
 
 The loop loads its weight fragments with inline-assembly ``global_load_dwordx4`` and waits for them
 with hand-counted ``s_waitcnt vmcnt(N)``. That is only sound if, between a load and the MFMAs that
-consume it, nothing else touches the destination registers and no memory instruction the counts do
-not know about is issued: a register copy made before the data has landed would copy stale bits, a
+consume it, nothing else touches the destination registers, a wait that covers the load comes before
+the first of those MFMAs, and no memory instruction the counts do not know about is issued: a register copy made before the data has landed would copy stale bits, a
 spill (scratch store / load) would shift every count. The compiler gives no such guarantee, so the
 generated code is inspected: hipcc cross-compiles gfx950 without a GPU."""
 import re
@@ -76,11 +76,21 @@ def test_weights_in_registers_loop_has_no_copies_spills_or_uncounted_memory_ops(
                 continue
             dst = _regs(loop[i].split()[1].rstrip(","))
             for r in dst:
+                # ... and by then a wait has let at most as many younger memory operations stay in
+                # flight as were issued after this load (vmcnt counts loads and LDS-DMA in issue order)
+                younger, covered = 0, False
                 for k in range(1, n + 1):
                     op2, t2 = touched[(i + k) % n]
+                    line2 = loop[(i + k) % n]
+                    if op2.startswith(("global_load", "buffer_load", "global_store", "buffer_store")):
+                        younger += 1
+                    elif op2 == "s_waitcnt":
+                        m = re.search(r"vmcnt\((\d+)\)", line2)
+                        covered = covered or (m is not None and int(m.group(1)) <= younger)
                     if r in t2:
                         assert op2.startswith("v_mfma"), (
-                            f"{name}: v{r} is loaded by `{loop[i]}` and next touched by `{loop[(i + k) % n]}`")
+                            f"{name}: v{r} is loaded by `{loop[i]}` and next touched by `{line2}`")
+                        assert covered, f"{name}: `{line2}` reads v{r} before a wait covers `{loop[i]}`"
                         break
         # memory operations of the loop: only the counted ones, and only the hand-written waits
         vmem = [l.split()[0] for l in loop if l.startswith(("global_", "buffer_", "flat_", "scratch_"))]
