@@ -465,15 +465,17 @@ def run_replica_workloads(ctx: Ctx, out: dict) -> None:
                 prefix_cache_hit_rate=round(float(hit), 3))
         # Interactive use (the reference's REPL answers one question at a time): latency of a
         # single question through the whole protocol with nothing else in flight.
-        panel = [Member(p, be_p, core.PromptTemplates(), gp_p, decision_mode="logprob") for p in personas[:4]]
-        solo = Coordinator(panel, sess)
-        lat1 = []
-        for i in range(4):
-            r1 = solo.ask(make_questions(rng, 1, a.proto_prompt_len)[0])
-            ctx.sync()
-            if i:
-                lat1.append(r1.latency_s * 1e3)
-        out["reference_protocol"]["single_question_latency_ms"] = round(float(np.median(lat1)), 1)
+        for key, templates in (("reference_protocol", core.PromptTemplates()),
+                               ("reference_protocol_persona_first", core.PromptTemplates.persona_first())):
+            panel = [Member(p, be_p, templates, gp_p, decision_mode="logprob") for p in personas[:4]]
+            solo = Coordinator(panel, sess)
+            lat1 = []
+            for i in range(4):
+                r1 = solo.ask(make_questions(rng, 1, a.proto_prompt_len)[0])
+                ctx.sync()
+                if i:
+                    lat1.append(r1.latency_s * 1e3)
+            out[key]["single_question_latency_ms"] = round(float(np.median(lat1)), 1)
 
 
 # ------------------------------------------------------------------------------------ configured ensembles
