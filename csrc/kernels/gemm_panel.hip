@@ -299,6 +299,146 @@ int launch_panel(int epi, const bf16_t* w, const bf16_t* x, void* Y, const bf16_
 }
 
 // ---------------------------------------------------------------------------------------------
+// 160-column workgroups. A matrix of 257-320 column tiles of 128 (Qwen2.5-7B's gate/up projection:
+// 37888 columns = 296 tiles) needs two rounds of one-workgroup-per-CU on 256 CUs, and the second
+// round keeps 40 CUs busy for as long as the first kept all of them: 59 us where the 271 MB of
+// weights would stream in ~45. With ten n-tiles (five gate/up pairs) per workgroup the same matrix
+// is 237 workgroups, one round. Waves 0-4 compute one pair each against all rows (MFMA time is
+// not binding at these heights even on five waves); every wave stages n-tile `wave`, waves 5 and 6, which compute
+// nothing, also stage n-tiles 8 and 9, so their K-tiles count two more DMA instructions (P2).
+// The last workgroup's n-tiles past the end of the matrix are staged from the last valid one
+// and never stored.
+template <int BM>
+struct Panel5Shape {
+  static constexpr int NT = 10, WBYTES = NT * 2048, STAGE = WBYTES + BM * 128;
+  static constexpr int NSTAGE = BM >= 256 ? 3 : (BM >= 128 ? 4 : (BM >= 64 ? 5 : 6));   // 156 / 144 / 140 / 144 KiB
+  static constexpr int DEPTH = NSTAGE - 1;
+  static constexpr int MT_W = BM / 16;
+  static constexpr int XP = BM >= 64 ? BM / 64 : 1;         // X pieces a wave stages per K-tile
+  static constexpr int P = 2 + XP, P2 = 4 + XP;             // DMA instructions per wave and K-tile
+};
+
+template <int BM, int EPI>
+__global__ __launch_bounds__(512) void gemm_panel5_kernel(const bf16_t* __restrict__ Wp,
+                                                          const bf16_t* __restrict__ X, void* __restrict__ Y,
+                                                          const bf16_t* __restrict__ bias, int M, int N, int K,
+                                                          int ldy, int nt_total) {
+  using S = Panel5Shape<BM>;
+  static_assert(S::P2 * S::DEPTH <= 63, "vmcnt is a 6-bit counter");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int KT = K / 32, nk = K / GP_BK;
+  const int nt0 = static_cast<int>(blockIdx.x) * S::NT;
+  const bool two = wave == 5 || wave == 6;
+  const int t_a = min(nt0 + wave, nt_total - 1), t_b = min(nt0 + wave + 3, nt_total - 1);
+  const bf16_t* wsrc_a = Wp + static_cast<size_t>(t_a) * KT * 512 + lane * 8;
+  const bf16_t* wsrc_b = Wp + static_cast<size_t>(t_b) * KT * 512 + lane * 8;
+  const int rr = lane >> 3, lc = lane & 7;
+  const bf16_t* xsrc[S::XP];
+  int xdst[S::XP];
+#pragma unroll
+  for (int q = 0; q < S::XP; ++q) {
+    const int piece = (q * 8 + wave) % (BM / 8);
+    int xrow = piece * 8 + rr;
+    xrow = xrow < M ? xrow : M - 1;
+    xsrc[q] = X + static_cast<size_t>(xrow) * K + ((lc ^ rr) << 3);
+    xdst[q] = S::WBYTES + piece * 1024;
+  }
+  auto issue = [&](int t) {
+    if (t >= nk) return;
+    char* stage = smem + (t % S::NSTAGE) * S::STAGE;
+    __builtin_amdgcn_global_load_lds(LC_GLOBAL_PTR(wsrc_a + t * 1024), LC_LDS_PTR(stage + wave * 2048), 16, 0, GP_NT);
+    __builtin_amdgcn_global_load_lds(LC_GLOBAL_PTR(wsrc_a + t * 1024 + 512), LC_LDS_PTR(stage + wave * 2048 + 1024),
+                                     16, 0, GP_NT);
+    if (two) {
+      __builtin_amdgcn_global_load_lds(LC_GLOBAL_PTR(wsrc_b + t * 1024), LC_LDS_PTR(stage + (wave + 3) * 2048), 16, 0,
+                                       GP_NT);
+      __builtin_amdgcn_global_load_lds(LC_GLOBAL_PTR(wsrc_b + t * 1024 + 512),
+                                       LC_LDS_PTR(stage + (wave + 3) * 2048 + 1024), 16, 0, GP_NT);
+    }
+#pragma unroll
+    for (int q = 0; q < S::XP; ++q)
+      __builtin_amdgcn_global_load_lds(LC_GLOBAL_PTR(xsrc[q] + t * GP_BK), LC_LDS_PTR(stage + xdst[q]), 16, 0, 0);
+  };
+
+  f32x4 acc[2][S::MT_W];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < S::MT_W; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int t = 0; t < S::DEPTH; ++t) issue(t);
+
+  for (int t = 0; t < nk; ++t) {
+    const int behind = nk - 1 - t;
+    const int flight = behind < S::DEPTH - 1 ? behind : S::DEPTH - 1;
+    if (two) gp_wait_tiles_in_flight<S::P2>(flight);
+    else gp_wait_tiles_in_flight<S::P>(flight);
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    issue(t + S::DEPTH);
+    if (wave < 5) {
+      const char* stage = smem + (t % S::NSTAGE) * S::STAGE;
+      const char* wimg = stage + (wave * 2) * 2048 + lane * 16;
+      const char* ximg = stage + S::WBYTES;
+      // one 32-deep k-step at a time: at 256 rows both steps' activation fragments would not fit
+      // next to the 128 accumulator registers
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt) {
+        bf16x8 a[2], b[S::MT_W];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) a[i] = *reinterpret_cast<const bf16x8*>(wimg + i * 2048 + kt * 1024);
+#pragma unroll
+        for (int j = 0; j < S::MT_W; ++j) b[j] = *reinterpret_cast<const bf16x8*>(ximg + gp_x_off(j, kt, lane));
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int j = 0; j < S::MT_W; ++j)
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+      }
+    }
+  }
+  if (wave >= 5) return;
+  const int nbase = blockIdx.x * (S::NT * 16) + wave * 32;
+#pragma unroll
+  for (int j = 0; j < S::MT_W; ++j) {
+    if constexpr (EPI == EPI_SWIGLU) {
+      store_tile<EPI>(acc[0][j], &acc[1][j], Y, bias, j * 16, nbase, M, N, ldy, lane, 0);
+    } else {
+      store_tile<EPI>(acc[0][j], nullptr, Y, bias, j * 16, nbase, M, N, ldy, lane, 0);
+      store_tile<EPI>(acc[1][j], nullptr, Y, bias, j * 16, nbase + 16, M, N, ldy, lane, 0);
+    }
+  }
+}
+
+template <int BM>
+int launch_panel5(int epi, const bf16_t* w, const bf16_t* x, void* Y, const bf16_t* b, int M, int N, int K,
+                  int n_pad, int ldy, hipStream_t stream) {
+  using S = Panel5Shape<BM>;
+  const int nt_total = n_pad / 16;
+  const dim3 grid((nt_total + S::NT - 1) / S::NT), block(512);
+  const int lds = S::NSTAGE * S::STAGE;
+  static LcDeviceOnce attr_once;
+  attr_once.run([&] {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_panel5_kernel<BM, EPI_BF16>),
+                        hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_panel5_kernel<BM, EPI_SWIGLU>),
+                        hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  });
+  if (epi == EPI_BF16)
+    gemm_panel5_kernel<BM, EPI_BF16><<<grid, block, lds, stream>>>(w, x, Y, b, M, N, K, ldy, nt_total);
+  else if (epi == EPI_SWIGLU)
+    gemm_panel5_kernel<BM, EPI_SWIGLU><<<grid, block, lds, stream>>>(w, x, Y, b, M, N, K, ldy, nt_total);
+  else
+    return -2;
+  return static_cast<int>(hipGetLastError());
+}
+
+// ---------------------------------------------------------------------------------------------
 // Grouped form for MoE decode steps: blockIdx.z selects an expert; the expert's rows are
 // offsets[e] .. offsets[e+1] of the expert-sorted token list (optionally gathered from X through
 // row_index), its weights start at Wp_all + e * expert_stride. A decode step routes a few dozen
@@ -449,6 +589,16 @@ LC_EXPORT int lc_gemm_panel(const void* Wp, const void* X, void* Y, const void* 
 #define LC_PANEL(BM_)                                                                            \
   return deep ? launch_panel<BM_, true>(epi, w, x, Y, b, M, N, K, n_pad, ldy, splits, stream)    \
               : launch_panel<BM_, false>(epi, w, x, Y, b, M, N, K, n_pad, ldy, splits, stream)
+  // Wide outputs whose 128-column tiles need a second, mostly empty round on the 256 CUs take
+  // 160-column workgroups instead when that saves the round (deep = 2 asks for it; the caller
+  // knows whether the GEMM has the GPU to itself).
+  if (deep == 2) {
+    if (splits != 1 || epi == EPI_F32) return -1;
+    if (M <= 32) return launch_panel5<32>(epi, w, x, Y, b, M, N, K, n_pad, ldy, stream);
+    if (M <= 64) return launch_panel5<64>(epi, w, x, Y, b, M, N, K, n_pad, ldy, stream);
+    if (M <= 128) return launch_panel5<128>(epi, w, x, Y, b, M, N, K, n_pad, ldy, stream);
+    return launch_panel5<256>(epi, w, x, Y, b, M, N, K, n_pad, ldy, stream);   // correct, but not faster than 256x256 tiles
+  }
   if (M <= 32) LC_PANEL(32);
   if (M <= 64) LC_PANEL(64);
   if (M <= 128) LC_PANEL(128);

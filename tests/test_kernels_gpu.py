@@ -713,6 +713,40 @@ def test_gemm_panel_kernel(M, N, K, swiglu, bias, splits, deep):
         assert torch.equal(y, run())
 
 
+@pytest.mark.parametrize("M,N,K,swiglu,bias", [
+    (64, 37888, 512, True, False), (33, 37888, 256, True, True), (17, 33280, 192, False, True),
+    (64, 40960, 128, False, False), (1, 33024, 320, True, False), (100, 37888, 256, True, False),
+    (129, 33280, 192, False, True), (256, 37888, 320, True, True), (200, 40960, 64, False, False)])
+def test_gemm_panel_with_160_column_workgroups(M, N, K, swiglu, bias, monkeypatch):
+    """Matrices of 257-320 column tiles of 128 take workgroups of 160 columns (ten n-tiles, five
+    gate/up pairs) so that one round of workgroups covers them; the last workgroup is partly past
+    the end of the matrix. Same bits as the 128-column kernel (same accumulation order)."""
+    W = bf(rand(N, K, scale=0.1, seed=21))
+    b = bf(rand(N, seed=22)) if bias else None
+    x = bf(rand(M, K, scale=0.5, seed=23))
+    lw = ops.LinearWeight.from_dense(W, b, DEV, swiglu=swiglu)
+    xd = x.to(DEV)
+    from llm_consensus_amd.ops import hip as h
+
+    out_n = N // 2 if swiglu else N
+    y = torch.empty(M, out_n, dtype=torch.bfloat16, device=DEV)
+    wide = lambda out: h.call("lc_gemm_panel", lw.data.data_ptr(), xd.data_ptr(), out.data_ptr(), h.ptr(lw.bias), M, N, K,  # noqa: E731
+                              lw.n_pad, out_n, ops.EPI_SWIGLU if swiglu else ops.EPI_BF16, 1, 2)
+    wide(y)
+    monkeypatch.setattr(ops, "PANEL_WIDE", False)
+    y128 = ops.linear(xd, lw)                 # 128-column panel kernel (256x256 tiles above 128 rows)
+    assert torch.equal(y, y128)
+    monkeypatch.setattr(ops, "PANEL_WIDE", True)
+    if M <= 128:
+        assert torch.equal(y, ops.linear(xd, lw))      # what the op layer picks for these shapes
+    want = ops.linear(x, ops.LinearWeight.from_dense(W, b, "cpu", swiglu=swiglu), out_f32=True)
+    assert rel_err(y.float().cpu(), want) < 1e-2
+    for _ in range(10):
+        again = torch.empty_like(y)
+        wide(again)
+        assert torch.equal(y, again)
+
+
 def test_moe_experts_with_skewed_routing_covers_row_blocks():
     """All tokens routed to two of eight experts: the grouped panel kernel sizes its panels for
     the mean load, so the busy experts need several row blocks each; idle experts need none."""
