@@ -303,9 +303,9 @@ int launch_panel(int epi, const bf16_t* w, const bf16_t* x, void* Y, const bf16_
 // 37888 columns = 296 tiles) needs two rounds of one-workgroup-per-CU on 256 CUs, and the second
 // round keeps 40 CUs busy for as long as the first kept all of them: 59 us where the 271 MB of
 // weights would stream in ~45. With ten n-tiles (five gate/up pairs) per workgroup the same matrix
-// is 237 workgroups, one round. Waves 0-4 compute one pair each against all rows (MFMA time is
-// not binding at these heights even on five waves); every wave stages n-tile `wave`, waves 5 and 6, which compute
-// nothing, also stage n-tiles 8 and 9, so their K-tiles count two more DMA instructions (P2).
+// is 237 workgroups, one round. Up to 64 rows waves 0-4 compute one pair each against all rows
+// (MFMA time is far from binding there) and waves 5-7 only stage; every wave stages n-tile `wave`,
+// waves 5 and 6 also stage n-tiles 8 and 9, so their K-tiles count two more DMA instructions (P2).
 // The last workgroup's n-tiles past the end of the matrix are staged from the last valid one
 // and never stored.
 template <int BM>
@@ -316,6 +316,12 @@ struct Panel5Shape {
   static constexpr int MT_W = BM / 16;
   static constexpr int XP = BM >= 64 ? BM / 64 : 1;         // X pieces a wave stages per K-tile
   static constexpr int P = 2 + XP, P2 = 4 + XP;             // DMA instructions per wave and K-tile
+  // From 128 rows on, 32-64 MFMAs per K-tile on each of five waves no longer hide behind the weight
+  // stream, so the rows are split over all eight waves instead (one or two row tiles x ten n-tiles
+  // per wave): Qwen2.5-7B gate/up at 128 rows 59.9 -> 54.6 us, at 256 rows 104 -> 85-88 us
+  static constexpr bool MSPLIT = BM >= 128;
+  static constexpr int NT_C = MSPLIT ? NT : 2;              // n-tiles a computing wave covers
+  static constexpr int MT_C = MSPLIT ? BM / 128 : MT_W;     // ... and row tiles
 };
 
 template <int BM, int EPI>
@@ -362,11 +368,14 @@ __global__ __launch_bounds__(512) void gemm_panel5_kernel(const bf16_t* __restri
       __builtin_amdgcn_global_load_lds(LC_GLOBAL_PTR(xsrc[q] + t * GP_BK), LC_LDS_PTR(stage + xdst[q]), 16, 0, 0);
   };
 
-  f32x4 acc[2][S::MT_W];
+  f32x4 acc[S::NT_C][S::MT_C];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < S::NT_C; ++i)
 #pragma unroll
-    for (int j = 0; j < S::MT_W; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < S::MT_C; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const bool computes = S::MSPLIT || wave < 5;
+  const int nt_w = S::MSPLIT ? 0 : wave * 2;                // first n-tile (within the workgroup) of this wave
+  const int mt_w = S::MSPLIT ? wave * S::MT_C : 0;          // first row tile
 #pragma unroll
   for (int t = 0; t < S::DEPTH; ++t) issue(t);
 
@@ -379,40 +388,43 @@ __global__ __launch_bounds__(512) void gemm_panel5_kernel(const bf16_t* __restri
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     issue(t + S::DEPTH);
-    if (wave < 5) {
+    if (computes) {
       const char* stage = smem + (t % S::NSTAGE) * S::STAGE;
-      const char* wimg = stage + (wave * 2) * 2048 + lane * 16;
+      const char* wimg = stage + nt_w * 2048 + lane * 16;
       const char* ximg = stage + S::WBYTES;
-      // one 32-deep k-step at a time: at 256 rows both steps' activation fragments would not fit
-      // next to the 128 accumulator registers
+      // one 32-deep k-step at a time keeps the fragment registers of a step few
 #pragma unroll
       for (int kt = 0; kt < 2; ++kt) {
-        bf16x8 a[2], b[S::MT_W];
+        bf16x8 a[S::NT_C], b[S::MT_C];
 #pragma unroll
-        for (int i = 0; i < 2; ++i) a[i] = *reinterpret_cast<const bf16x8*>(wimg + i * 2048 + kt * 1024);
+        for (int i = 0; i < S::NT_C; ++i) a[i] = *reinterpret_cast<const bf16x8*>(wimg + i * 2048 + kt * 1024);
 #pragma unroll
-        for (int j = 0; j < S::MT_W; ++j) b[j] = *reinterpret_cast<const bf16x8*>(ximg + gp_x_off(j, kt, lane));
+        for (int j = 0; j < S::MT_C; ++j)
+          b[j] = *reinterpret_cast<const bf16x8*>(ximg + gp_x_off(mt_w + j, kt, lane));
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-        for (int j = 0; j < S::MT_W; ++j)
+        for (int j = 0; j < S::MT_C; ++j)
 #pragma unroll
-          for (int i = 0; i < 2; ++i)
+          for (int i = 0; i < S::NT_C; ++i)
             acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
         __builtin_amdgcn_s_setprio(0);
       }
     }
   }
-  if (wave >= 5) return;
-  const int nbase = blockIdx.x * (S::NT * 16) + wave * 32;
+  if (!computes) return;
+  const int nbase = blockIdx.x * (S::NT * 16) + nt_w * 16;
 #pragma unroll
-  for (int j = 0; j < S::MT_W; ++j) {
-    if constexpr (EPI == EPI_SWIGLU) {
-      store_tile<EPI>(acc[0][j], &acc[1][j], Y, bias, j * 16, nbase, M, N, ldy, lane, 0);
-    } else {
-      store_tile<EPI>(acc[0][j], nullptr, Y, bias, j * 16, nbase, M, N, ldy, lane, 0);
-      store_tile<EPI>(acc[1][j], nullptr, Y, bias, j * 16, nbase + 16, M, N, ldy, lane, 0);
+  for (int j = 0; j < S::MT_C; ++j)
+#pragma unroll
+    for (int i = 0; i < S::NT_C; i += 2) {
+      const int m0 = (mt_w + j) * 16;
+      if constexpr (EPI == EPI_SWIGLU) {
+        store_tile<EPI>(acc[i][j], &acc[i + 1][j], Y, bias, m0, nbase + i * 16, M, N, ldy, lane, 0);
+      } else {
+        store_tile<EPI>(acc[i][j], nullptr, Y, bias, m0, nbase + i * 16, M, N, ldy, lane, 0);
+        store_tile<EPI>(acc[i + 1][j], nullptr, Y, bias, m0, nbase + (i + 1) * 16, M, N, ldy, lane, 0);
+      }
     }
-  }
 }
 
 template <int BM>
@@ -597,7 +609,7 @@ LC_EXPORT int lc_gemm_panel(const void* Wp, const void* X, void* Y, const void* 
     if (M <= 32) return launch_panel5<32>(epi, w, x, Y, b, M, N, K, n_pad, ldy, stream);
     if (M <= 64) return launch_panel5<64>(epi, w, x, Y, b, M, N, K, n_pad, ldy, stream);
     if (M <= 128) return launch_panel5<128>(epi, w, x, Y, b, M, N, K, n_pad, ldy, stream);
-    return launch_panel5<256>(epi, w, x, Y, b, M, N, K, n_pad, ldy, stream);   // correct, but not faster than 256x256 tiles
+    return launch_panel5<256>(epi, w, x, Y, b, M, N, K, n_pad, ldy, stream);
   }
   if (M <= 32) LC_PANEL(32);
   if (M <= 64) LC_PANEL(64);

@@ -34,6 +34,7 @@ PANEL_MIN_KTILES = int(os.environ.get("LC_PANEL_MIN_KTILES", "4"))
 # concurrent streams). Chosen when a decode graph is captured; see set_concurrent_engines().
 PANEL_DEEP = os.environ.get("LC_PANEL_DEEP", "1") == "1"
 PANEL_WIDE = os.environ.get("LC_PANEL_WIDE", "1") == "1"   # 160-column workgroups where they save a round (see linear())
+PANEL_WIDE_MAX_M = int(os.environ.get("LC_PANEL_WIDE_MAX_M", "256"))
 
 
 # Decode attention: how many of the KV splits the waves of one workgroup may take (1, 2 or 4).
@@ -268,9 +269,8 @@ def linear(x: torch.Tensor, w: LinearWeight, out_f32: bool = False, defer_reduce
         return y
     # 257..320 column tiles of 128 (Qwen2.5-7B gate/up: 296): a second round would keep 40 CUs busy
     # as long as the first kept 256; workgroups of 160 columns cover the matrix in one round
-    # (up to 128 rows: at 256 the five computing waves of such a workgroup no longer keep up, measured
-    # 104 us against 100 for the 256x256 tiles below on that matrix)
-    wide = (PANEL_WIDE and DECODE_KERNEL == "panel" and M <= 128 and epi != EPI_F32 and w.n_pad // 128 > 256
+    # (at 256 rows 85-88 us against 100 for the 256x256 tiles below on that matrix)
+    wide = (PANEL_WIDE and DECODE_KERNEL == "panel" and M <= PANEL_WIDE_MAX_M and epi != EPI_F32 and w.n_pad // 128 > 256
             and (w.n_pad // 16 + 9) // 10 <= 256 and _choose_panel_splits(w.n_pad, w.k) == 1)
     # 129..256 rows against more than 256 column tiles (vocabulary projection, very wide gate/up):
     # a second round of 128-column tiles would start; 256x256 tiles (half as many) do better.
