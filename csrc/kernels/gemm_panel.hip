@@ -589,7 +589,8 @@ int launch_panel_grouped(int epi, const bf16_t* w, long long stride, const bf16_
 
 // Y[M<=256, N] = X * W^T. Requirements: K % 64 == 0, (K/64) % splits == 0, n_pad % 128 == 0.
 // splits > 1 requires epi == EPI_F32 and Y = fp32 workspace [splits, M, ldy]. deep = 0 selects the
-// three-stage ring (two workgroups per CU) for M <= 128.
+// three-stage ring (two workgroups per CU) for M <= 128; deep = 2 the 160-column workgroups
+// (splits == 1, bf16 or SwiGLU epilogue; n_pad need not be a multiple of 160).
 LC_EXPORT int lc_gemm_panel(const void* Wp, const void* X, void* Y, const void* bias, int M, int N, int K,
                             int n_pad, int ldy, int epi, int splits, int deep, hipStream_t stream) {
   if (M <= 0) return 0;
