@@ -221,6 +221,14 @@ class PartialSum:
         return y
 
 
+def use_wide_panel(M: int, n_pad: int, k: int) -> bool:
+    """Whether a decode GEMM of ``M`` rows against ``n_pad`` columns takes the 160-column workgroups:
+    its 128-column tiles would need a second round on the 256 CUs (and K is not split), while
+    ten-n-tile workgroups cover it in one."""
+    return (PANEL_WIDE and DECODE_KERNEL == "panel" and M <= PANEL_WIDE_MAX_M and n_pad // 128 > 256
+            and (n_pad // 16 + 9) // 10 <= 256 and _choose_panel_splits(n_pad, k) == 1)
+
+
 def linear(x: torch.Tensor, w: LinearWeight, out_f32: bool = False, defer_reduce: bool = False):
     """y = x @ W^T (+bias). With ``w.swiglu`` returns silu(gate)*up of width N/2. With
     ``defer_reduce`` a split-K product may come back as a ``PartialSum``."""
@@ -270,8 +278,7 @@ def linear(x: torch.Tensor, w: LinearWeight, out_f32: bool = False, defer_reduce
     # 257..320 column tiles of 128 (Qwen2.5-7B gate/up: 296): a second round would keep 40 CUs busy
     # as long as the first kept 256; workgroups of 160 columns cover the matrix in one round
     # (at 256 rows 85-88 us against 100 for the 256x256 tiles below on that matrix)
-    wide = (PANEL_WIDE and DECODE_KERNEL == "panel" and M <= PANEL_WIDE_MAX_M and epi != EPI_F32 and w.n_pad // 128 > 256
-            and (w.n_pad // 16 + 9) // 10 <= 256 and _choose_panel_splits(w.n_pad, w.k) == 1)
+    wide = epi != EPI_F32 and use_wide_panel(M, w.n_pad, w.k)
     # 129..256 rows against more than 256 column tiles (vocabulary projection, very wide gate/up):
     # a second round of 128-column tiles would start; 256x256 tiles (half as many) do better.
     if M > 128 and not wide and w.n_pad // 128 > 256 and w.n_pad % 256 == 0 and GEMM256_MIN_TILES >= 0:
