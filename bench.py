@@ -8,7 +8,17 @@ children (one per GPU, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, rendezvous
 127.0.0.1) before anything touches a GPU, relays rank 0's output and exits with the worst
 child status. Under ``python -m torch.distributed.run --nproc-per-node N bench.py --gpus N``
 it is one of the ranks. Fewer visible GPUs than ``--gpus``, or a WORLD_SIZE that disagrees
-with it, is an error (never a silent 1-GPU run). Rank 0 prints ONE JSON line.
+with it, is an error (never a silent 1-GPU run). Rank 0 prints the result as ONE JSON line, the
+LAST line of its output. As soon as the headline workload is measured, and again after every
+further section, it also prints the line as it stands so far (marked ``"provisional"``): a run
+that is cut short by a time limit has still reported everything it measured.
+
+Time budget on a multi-GPU node (defaults): A, B and C take ~150 s; the sections that run in
+child processes (A with one model per GPU, D, E) share ``--isolated-budget`` 390 s, each attempt
+at most ``--section-timeout`` 150 s, and an attempt is only started with a minute left: the
+whole run stays under 150 + 390 = 540 s whatever stalls. A model group's own collectives give
+up waiting for a peer after LC_P2P_TIMEOUT_S (10 s here) and a group whose first exchange fails
+its self-check falls back to RCCL inside the same process (parallel/p2p.py).
 
 Workloads (llm_consensus_amd/workloads.py; random-init bf16 weights of the named shapes,
 synthetic multiple-choice prompts, every new token really sampled):
@@ -46,6 +56,9 @@ ROOT = Path(__file__).resolve().parent
 if str(ROOT) not in sys.path:
     sys.path.insert(0, str(ROOT))
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+# A peer that never shows up is noticed after this many seconds (the library's default of 60 s
+# suits a server; a benchmark section has 150 s in all).
+os.environ.setdefault("LC_P2P_TIMEOUT_S", "10")
 
 REFERENCE_BOUND_ANSWERS_PER_S = 0.2  # derived upper bound for the reference (it publishes no numbers)
 ALL_WORKLOADS = "ABCDE"
@@ -74,7 +87,7 @@ def parse_args(argv=None):
     ap.add_argument("--poisson-load", type=float, default=0.7,
                     help="open-loop run of workload A: arrival rate as a fraction of the closed-loop rate (0 = skip)")
     ap.add_argument("--poisson-seconds", type=float, default=10.0, help="length of the arrival trace")
-    ap.add_argument("--aux-steps", type=int, default=None, help="timed steps of C, D, E (default: min(steps, 6))")
+    ap.add_argument("--aux-steps", type=int, default=None, help="timed steps of C, D, E (default: min(steps, 6), min(steps, 4) with several GPUs)")
     ap.add_argument("--proto-questions", type=int, default=8, help="questions per GPU per step (workload C)")
     ap.add_argument("--proto-prompt-len", type=int, default=128)
     ap.add_argument("--judge-questions", type=int, default=16, help="questions per GPU per step (workload D)")
@@ -96,9 +109,9 @@ def parse_args(argv=None):
     ap.add_argument("--out", default=None, help="also write the JSON line to this file")
     ap.add_argument("--skip-spread", action="store_true",
                     help="multi-GPU runs: skip the extra run of workload A with one model per GPU")
-    ap.add_argument("--section-timeout", type=float, default=300.0,
+    ap.add_argument("--section-timeout", type=float, default=150.0,
                     help="multi-GPU runs: seconds a sharded workload (D, E) may take before it is abandoned")
-    ap.add_argument("--isolated-budget", type=float, default=720.0,
+    ap.add_argument("--isolated-budget", type=float, default=390.0,
                     help="multi-GPU runs: seconds all child-process sections together may take; what is left "
                          "bounds each attempt, and a section that finds less than a minute left is skipped")
     ap.add_argument("--share-gpu", action="store_true",
@@ -112,7 +125,8 @@ def parse_args(argv=None):
         ap.error(f"--workload takes letters out of {ALL_WORKLOADS}")
     a.workloads = wl
     if a.aux_steps is None:
-        a.aux_steps = min(a.steps, 6)
+        # multi-GPU runs time fewer steps of C, D and E: their sections share a fixed time budget
+        a.aux_steps = min(a.steps, 6 if a.gpus == 1 else 4)
     return a
 
 
@@ -247,6 +261,39 @@ def section(metric, el, n, lat, steps, **extra):
     return d
 
 
+def section_done(ctx: Ctx, out: dict, label: str) -> None:
+    """Marks a section as measured and reports the line so far when others are still to come."""
+    todo = ctx.todo
+    if label in todo:
+        todo.remove(label)
+    if todo:
+        emit(ctx, out, ", ".join(todo))
+
+
+def emit(ctx: Ctx, out: dict, pending: str = "") -> None:
+    """Rank 0 prints the result line as it stands. ``pending`` names what is still to be
+    measured (the line is then marked provisional); the final call passes nothing."""
+    if ctx.rank != 0:
+        return
+    d = dict(out)
+    if "A" not in ctx.a.workloads:
+        # no headline run requested: promote the first measured section so the line stays well formed
+        for key in ("self_consistency", "reference_protocol", "judge_consensus", "moe_medoid"):
+            if key in d and "value" in d[key]:
+                d.update({"metric": d[key]["metric"], "value": d[key]["value"],
+                          "ms_per_step": d[key]["ms_per_step"], "steps": d[key]["steps"]})
+                break
+    if d.get("value") is not None:
+        d["vs_baseline"] = round(d["value"] / REFERENCE_BOUND_ANSWERS_PER_S, 1)
+    if pending:
+        d["provisional"] = f"still to come: {pending}"
+    line = json.dumps(d)
+    print(line, flush=True)
+    if ctx.a.out:
+        Path(ctx.a.out).parent.mkdir(parents=True, exist_ok=True)
+        Path(ctx.a.out).write_text(line + "\n")
+
+
 # ------------------------------------------------------------------------------------ A, B, C
 def run_replica_workloads(ctx: Ctx, out: dict) -> None:
     """A (replica placement), B and C: every rank hosts its own engines; ranks exchange winners."""
@@ -311,8 +358,9 @@ def run_replica_workloads(ctx: Ctx, out: dict) -> None:
         out["member_engines"] = {
             names[i]: {k: round(st1[i].get(k, 0.0) - st0[i].get(k, 0.0), 3)
                        for k in ("prefill.steps", "prefill.seconds", "decode.steps", "decode.seconds",
-                                 "decode.wait_seconds", "prefill.rider_tokens")}
+                                 "decode.wait_seconds", "prefill.rider_tokens", "decode.ahead_steps")}
             for i in range(len(names))}
+        section_done(ctx, out, "A")
         if not a.skip_stream:
             # The same ensemble as a service under load: a closed loop keeps ``in_flight``
             # questions in the engines at all times; every finished question is replaced by a new
@@ -352,6 +400,7 @@ def run_replica_workloads(ctx: Ctx, out: dict) -> None:
                 "p50_latency_ms": pct(lat_s, 50), "p95_latency_ms": pct(lat_s, 95),
                 "preemptions": int(sum(m.backend.stats().get("sched.preemptions", 0) for m in members)),
             }
+            section_done(ctx, out, "A.standing_queue")
             if a.poisson_load > 0:
                 # Open loop: questions arrive as a Poisson process at a fraction of the closed-loop
                 # rate just measured (each rank draws its own arrival trace), are admitted the moment
@@ -392,6 +441,7 @@ def run_replica_workloads(ctx: Ctx, out: dict) -> None:
                     "p50_latency_ms": pct(lat_o, 50), "p95_latency_ms": pct(lat_o, 95),
                     "p99_latency_ms": pct(lat_o, 99), "peak_in_flight_per_gpu": int(peak),
                 }
+                section_done(ctx, out, "A.poisson_arrivals")
     if "B" in wl:
         sc = SelfConsistency(members[0], k_chains=a.k_chains, choices="ABCD", decision_mode="logprob",
                              device=dev if ctx.cuda else None)
@@ -413,7 +463,9 @@ def run_replica_workloads(ctx: Ctx, out: dict) -> None:
             prompt_kv_reads_saved=round(1.0 - 1.0 / a.k_chains, 3), cow_copies=int(d("kv.cow_copies_total")),
             decode_ms_per_step=round(1e3 * d("decode.seconds") / max(1.0, d("decode.steps")), 3),
             decode_host_us_per_step={k: round(1e6 * d(f"host.{k}_seconds") / max(1.0, d("decode.steps")), 1)
-                                     for k in ("schedule", "decode_fill", "decode_launch", "decode_finish")})
+                                     for k in ("schedule", "decode_fill", "decode_launch", "decode_finish")},
+            decode_steps_launched_ahead=round(d("decode.ahead_steps") / max(1.0, d("decode.steps")), 3))
+        section_done(ctx, out, "B")
     if "C" in wl and a.proto_questions > 0:
         # The reference's own topology and loop: four personas share ONE model, a random member
         # proposes, everyone (proposer included) judges, a random dissenter refines, at most five
@@ -476,6 +528,7 @@ def run_replica_workloads(ctx: Ctx, out: dict) -> None:
                 if i:
                     lat1.append(r1.latency_s * 1e3)
             out[key]["single_question_latency_ms"] = round(float(np.median(lat1)), 1)
+        section_done(ctx, out, "C")
 
 
 # ------------------------------------------------------------------------------------ configured ensembles
@@ -637,6 +690,14 @@ def main(argv=None) -> int:
         },
         "workloads": wl,
     }
+    isolate = ctx.world > 1 and not a.in_child
+    spread_extra = (isolate and "A" in wl and a.placement == "replica" and ctx.world >= len(names)
+                    and not a.skip_spread)
+    ctx.todo = [lab for lab, on in (
+        ("A", "A" in wl), ("A.standing_queue", "A" in wl and a.placement == "replica" and not a.skip_stream),
+        ("A.poisson_arrivals", "A" in wl and a.placement == "replica" and not a.skip_stream and a.poisson_load > 0),
+        ("B", "B" in wl), ("C", "C" in wl and a.proto_questions > 0), ("A.one_model_per_gpu", spread_extra),
+        ("D", "D" in wl), ("E", "E" in wl)) if on]
     if a.share_gpu:
         out["rehearsal"] = f"{ctx.world} ranks share ONE GPU (gloo process group, host-staged tensors): not a measurement"
     samp = W.sampling(a.temperature, a.top_p, a.new_tokens)
@@ -652,6 +713,7 @@ def main(argv=None) -> int:
         out["config"].update({"global_batch": a.questions * rep, "placement": sec["placement"],
                               "parallelism": f"{rep} replica(s) x {len(names)} GPUs, one model per GPU"})
         wl_local = wl.replace("A", "")
+        section_done(ctx, out, "A")
     else:
         wl_local = wl
     if any(w in wl_local for w in "ABC"):
@@ -662,8 +724,7 @@ def main(argv=None) -> int:
     if out["value"] is not None:
         out["vs_baseline"] = round(out["value"] / REFERENCE_BOUND_ANSWERS_PER_S, 1)
     aux_warm = min(a.warmup, 1)
-    isolate = ctx.world > 1 and not a.in_child
-    if isolate and "A" in wl and a.placement == "replica" and ctx.world >= len(names) and not a.skip_spread:
+    if spread_extra:
         # The same ensemble with ONE MODEL PER GPU (replicas of len(models) GPUs, the members of a
         # replica answer concurrently on their own devices and publish their results to each
         # other): lower latency per question, fewer GPUs busy than with a full ensemble per GPU.
@@ -674,6 +735,7 @@ def main(argv=None) -> int:
                     "global_batch": full["config"]["global_batch"], "placement": full["config"].get("placement")}
 
         out["ensemble_one_model_per_gpu"] = run_isolated(ctx, a, argv, "A", ("--placement", "spread"), pick)
+        section_done(ctx, out, "A.one_model_per_gpu")
     if "D" in wl:
         if isolate:
             out["judge_consensus"] = run_isolated(ctx, a, argv, "D")
@@ -689,6 +751,7 @@ def main(argv=None) -> int:
                 ctx, cfg, nq, a.prompt_len, a.aux_steps, aux_warm,
                 f"consensus answers/sec, 4x {a.proposer_model} proposers + {a.judge_model} judge (log-prob scoring)",
                 judge_tp=cfg.models["judge"].tp, proposers=4)
+        section_done(ctx, out, "D")
     if "E" in wl:
         if isolate:
             out["moe_medoid"] = run_isolated(ctx, a, argv, "E")
@@ -701,20 +764,7 @@ def main(argv=None) -> int:
                 f"consensus answers/sec, {a.moe_model} proposer x{a.moe_samples} samples + {a.embed_model} embedding medoid",
                 expert_parallel=cfg.models["moe"].ep, ep_mode=cfg.models["moe"].ep_mode,
                 samples_per_question=a.moe_samples)
-    if "A" not in wl:
-        # no headline run requested: promote the first measured section so the line stays well formed
-        for key in ("self_consistency", "reference_protocol", "judge_consensus", "moe_medoid"):
-            if key in out and "value" in out[key]:
-                out.update({"metric": out[key]["metric"], "value": out[key]["value"],
-                            "ms_per_step": out[key]["ms_per_step"], "steps": out[key]["steps"]})
-                out["vs_baseline"] = round(out["value"] / REFERENCE_BOUND_ANSWERS_PER_S, 1)
-                break
-    if ctx.rank == 0:
-        line = json.dumps(out)
-        print(line, flush=True)
-        if a.out:
-            Path(a.out).parent.mkdir(parents=True, exist_ok=True)
-            Path(a.out).write_text(line + "\n")
+    emit(ctx, out)
     if ctx.dist is not None:
         ctx.dist.barrier()
         ctx.dist.destroy_process_group()

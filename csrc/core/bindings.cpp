@@ -309,6 +309,8 @@ PYBIND11_MODULE(_core, m) {
                              [](const StepPlan& p) { return to_array(p.group_shared_blocks); })
       .def_property_readonly("step_index", [](const StepPlan& p) { return to_array(p.step_index); })
       .def_property_readonly("seeds", [](const StepPlan& p) { return to_array(p.seeds); })
+      .def_readonly("ahead", &StepPlan::ahead)
+      .def_property_readonly("src_rows", [](const StepPlan& p) { return to_array(p.src_rows); })
       .def_property_readonly("copy_src", [](const StepPlan& p) { return to_array(p.copy_src); })
       .def_property_readonly("copy_dst", [](const StepPlan& p) { return to_array(p.copy_dst); });
   py::class_<Scheduler>(m, "Scheduler")
@@ -322,6 +324,7 @@ PYBIND11_MODULE(_core, m) {
            py::arg("params") = SamplingParams{})
       .def("abort_request", &Scheduler::abort_request)
       .def("schedule", &Scheduler::schedule)
+      .def("schedule_ahead", &Scheduler::schedule_ahead)
       .def("set_mix_decode", &Scheduler::set_mix_decode)
       .def_property_readonly("mix_decode", &Scheduler::mix_decode)
       .def("prefill_sample_layout", &Scheduler::prefill_sample_layout)
@@ -334,7 +337,7 @@ PYBIND11_MODULE(_core, m) {
            [](Scheduler& s, const StepPlan& plan, i32arr toks, f32arr lps) {
              if (toks.size() != static_cast<py::ssize_t>(plan.seq_ids.size()) || lps.size() != toks.size())
                throw std::invalid_argument("complete_decode: need one token and logprob per plan row");
-             s.complete_decode(plan, toks.data(), lps.data());
+             return to_array(s.complete_decode(plan, toks.data(), lps.data()));
            })
       .def("take_finished", &Scheduler::take_finished)
       .def("has_work", &Scheduler::has_work)

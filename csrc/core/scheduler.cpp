@@ -63,7 +63,15 @@ bool Scheduler::has_work() const {
 bool Scheduler::try_admit(Group& g) {
   if (promised_ + g.n > cfg_.max_batch_seqs) return false;
   if (cfg_.optimistic_admission) {
-    const int need = kv_->blocks_needed(static_cast<int>(g.prompt.size())) + g.n + cfg_.watermark_blocks;
+    // Blocks the prompt needs now, one per chain for the first generated tokens, and the blocks
+    // the chains that are already running take at their very next step (those standing at a
+    // block boundary): admitting a prompt into exactly those would make the next step preempt.
+    int next_step = 0;
+    const int bs = kv_->block_size();
+    for (int gid : running_)
+      for (const auto& c : groups_.at(gid).chains)
+        if (!c.done && kv_->num_tokens(c.seq) % bs == 0) ++next_step;
+    const int need = kv_->blocks_needed(static_cast<int>(g.prompt.size())) + g.n + next_step + cfg_.watermark_blocks;
     if (need > kv_->available_blocks() && promised_ > 0) return false;   // an empty engine always admits
   } else if (budget_used_ + g.budget_blocks > kv_->stats().blocks_total) {
     return false;
@@ -122,7 +130,9 @@ void Scheduler::preempt(int gid) {
 }
 
 void Scheduler::ensure_decode_capacity() {
-  // Oldest groups first; a group that cannot get its blocks takes them from the youngest.
+  // Oldest groups first; a group that cannot get its blocks takes them from the youngest
+  // admitted request: a prompt that is still being prefilled (it has produced nothing yet),
+  // then the youngest running group.
   for (size_t gi = 0; gi < running_.size(); ++gi) {
     const int gid = running_[gi];
     bool restart = true;
@@ -131,13 +141,12 @@ void Scheduler::ensure_decode_capacity() {
       Group& g = groups_.at(gid);
       for (auto& c : g.chains) {
         if (c.done || kv_->reserve(c.seq, 1)) continue;
-        // Victims: running groups younger than this one, then half-prefilled prompts, then
-        // (when this is the only group left) nobody: the request alone exceeds the pool.
-        if (running_.size() > gi + 1) {
-          preempt(running_.back());
-        } else if (!prefilling_.empty()) {
+        if (!prefilling_.empty()) {
           preempt(prefilling_.back());
+        } else if (running_.size() > gi + 1) {
+          preempt(running_.back());
         } else {
+          // this is the only group left: the request alone exceeds the pool
           throw std::runtime_error("Scheduler: KV pool too small for a single running request");
         }
         restart = true;
@@ -166,6 +175,11 @@ StepPlan Scheduler::schedule() {
   StepPlan plan;
   admit_waiting();
   const int bs = kv_->block_size();
+
+  // Mixed steps: the riders' blocks are secured BEFORE any prompt is laid out in the plan, so
+  // that a prompt admitted moments ago (whose blocks the riders now need) can still be the
+  // victim; it returns to the head of the waiting queue and the step goes on without it.
+  if (cfg_.mix_decode && !prefilling_.empty() && !running_.empty()) ensure_decode_capacity();
 
   if (!prefilling_.empty()) {
     plan.kind = StepPlan::Prefill;
@@ -216,19 +230,7 @@ StepPlan Scheduler::schedule() {
       budget -= take;
     }
     if (cfg_.mix_decode && !plan.seq_ids.empty() && !running_.empty()) {
-      // Room for the riders' tokens. Only running groups may be preempted here: the prompts
-      // of this step are already laid out in the plan.
-      {
-        std::vector<int> keep_prefilling;
-        keep_prefilling.swap(prefilling_);
-        try {
-          ensure_decode_capacity();
-        } catch (...) {
-          prefilling_.swap(keep_prefilling);
-          throw;
-        }
-        prefilling_.swap(keep_prefilling);
-      }
+      // The riders' blocks were reserved by the capacity pass at the top of this call.
       const int first = static_cast<int>(plan.seq_ids.size());
       for (int gid : running_) {
         Group& g = groups_.at(gid);
@@ -267,58 +269,93 @@ StepPlan Scheduler::schedule() {
   if (!running_.empty()) {
     ensure_decode_capacity();
   }
-  if (!running_.empty()) {
-    plan.kind = StepPlan::Decode;
-    for (int gid : running_) {
-      Group& g = groups_.at(gid);
-      const int first = static_cast<int>(plan.seq_ids.size());
-      int live = 0;
-      int min_pos = 1 << 30;
-      for (size_t k = 0; k < g.chains.size(); ++k) {
-        Chain& c = g.chains[k];
-        if (c.done) continue;
-        if (!kv_->reserve(c.seq, 1))
-          throw std::logic_error("Scheduler: block reservation lost between the capacity pass and the plan");
-        const int pos = kv_->num_tokens(c.seq);
-        const auto& bt = kv_->block_table(c.seq);
-        plan.seq_ids.push_back(c.seq);
-        plan.request_ids.push_back(gid);
-        plan.token_ids.push_back(c.last_token);
-        plan.positions.push_back(pos);
-        plan.slot_mapping.push_back(bt[pos / bs] * bs + pos % bs);
-        plan.context_lens.push_back(pos + 1);
-        plan.step_index.push_back(static_cast<int32_t>(c.out.size()));
-        plan.seeds.push_back(g.p.seed + k);
-        min_pos = std::min(min_pos, pos);
-        ++live;
+  if (!running_.empty()) build_decode_plan(plan, nullptr);
+  return plan;
+}
+
+bool Scheduler::build_decode_plan(StepPlan& plan, const std::unordered_map<int, int>* prev_rows) {
+  // prev_rows == nullptr: the ordinary decode step (blocks were reserved by the capacity pass).
+  // Otherwise the step AFTER one that is still in flight: every chain is one token further than
+  // the bookkeeping says, its input token is not known yet (src_rows names the row of the step
+  // in flight that samples it), and chains which that step ends by length are left out.
+  const int bs = kv_->block_size();
+  const int ahead = prev_rows ? 1 : 0;
+  plan.kind = StepPlan::Decode;
+  plan.ahead = ahead != 0;
+  for (int gid : running_) {
+    Group& g = groups_.at(gid);
+    const int first = static_cast<int>(plan.seq_ids.size());
+    int live = 0;
+    int min_pos = 1 << 30;
+    for (size_t k = 0; k < g.chains.size(); ++k) {
+      Chain& c = g.chains[k];
+      if (c.done) continue;
+      int src = -1;
+      if (ahead) {
+        if (static_cast<int>(c.out.size()) + 1 >= g.p.max_new_tokens) continue;   // ends in the step in flight
+        auto it = prev_rows->find(c.seq);
+        if (it == prev_rows->end()) return false;          // not part of the step in flight: no basis to run ahead
+        src = it->second;
       }
-      if (live == 0) continue;
-      int shared = 0;
-      if (live > 1) {
-        // Longest common prefix of the live chains' block tables, limited to blocks
-        // that are complete and no longer written by anyone.
-        const int limit = min_pos / bs;
-        const auto& bt0 = kv_->block_table(plan.seq_ids[first]);
-        shared = limit;
-        for (int r = first + 1; r < first + live; ++r) {
-          const auto& bt = kv_->block_table(plan.seq_ids[r]);
-          int m = 0;
-          while (m < shared && bt[m] == bt0[m]) ++m;
-          shared = m;
-        }
+      if (!kv_->reserve(c.seq, 1 + ahead)) {
+        if (ahead) return false;
+        throw std::logic_error("Scheduler: block reservation lost between the capacity pass and the plan");
       }
-      plan.group_first.push_back(first);
-      plan.group_count.push_back(live);
-      plan.group_shared_blocks.push_back(shared);
+      const int pos = kv_->num_tokens(c.seq) + ahead;
+      const auto& bt = kv_->block_table(c.seq);
+      plan.seq_ids.push_back(c.seq);
+      plan.request_ids.push_back(gid);
+      plan.token_ids.push_back(ahead ? 0 : c.last_token);
+      if (ahead) plan.src_rows.push_back(src);
+      plan.positions.push_back(pos);
+      plan.slot_mapping.push_back(bt[pos / bs] * bs + pos % bs);
+      plan.context_lens.push_back(pos + 1);
+      plan.step_index.push_back(static_cast<int32_t>(c.out.size()) + ahead);
+      plan.seeds.push_back(g.p.seed + k);
+      min_pos = std::min(min_pos, pos);
+      ++live;
     }
-    auto copies = kv_->take_pending_copies();
-    for (auto& c : copies) {
-      plan.copy_src.push_back(c.first);
-      plan.copy_dst.push_back(c.second);
+    if (live == 0) continue;
+    int shared = 0;
+    if (live > 1) {
+      // Longest common prefix of the live chains' block tables, limited to blocks
+      // that are complete and no longer written by anyone.
+      const int limit = min_pos / bs;
+      const auto& bt0 = kv_->block_table(plan.seq_ids[first]);
+      shared = limit;
+      for (int r = first + 1; r < first + live; ++r) {
+        const auto& bt = kv_->block_table(plan.seq_ids[r]);
+        int m = 0;
+        while (m < shared && bt[m] == bt0[m]) ++m;
+        shared = m;
+      }
     }
-    pack_block_tables(plan, *kv_);
-    return plan;
+    plan.group_first.push_back(first);
+    plan.group_count.push_back(live);
+    plan.group_shared_blocks.push_back(shared);
   }
+  auto copies = kv_->take_pending_copies();
+  for (auto& c : copies) {
+    plan.copy_src.push_back(c.first);
+    plan.copy_dst.push_back(c.second);
+  }
+  pack_block_tables(plan, *kv_);
+  return true;
+}
+
+StepPlan Scheduler::schedule_ahead(const StepPlan& inflight) {
+  StepPlan plan;
+  // Only a pure decode step with nothing waiting is continued blindly: a waiting or half-prefilled
+  // prompt wants the slots and blocks that the step in flight may free, and a mixed step's rows
+  // are not a decode batch.
+  if (inflight.kind != StepPlan::Decode || !waiting_.empty() || !prefilling_.empty() || running_.empty())
+    return plan;
+  std::unordered_map<int, int> rows;
+  rows.reserve(inflight.seq_ids.size() * 2);
+  for (size_t r = 0; r < inflight.seq_ids.size(); ++r) rows.emplace(inflight.seq_ids[r], static_cast<int>(r));
+  // A refusal half way leaves the blocks it reserved with their sequences (the ordinary step
+  // reserves the same ones next) and any queued block copy in the KV manager's queue.
+  if (!build_decode_plan(plan, &rows) || plan.seq_ids.empty()) return StepPlan();
   return plan;
 }
 
@@ -443,30 +480,54 @@ void Scheduler::complete_prefill(const StepPlan& plan, const int32_t* first_toke
   }
 }
 
-void Scheduler::complete_decode(const StepPlan& plan, const int32_t* tokens, const float* logprobs) {
+std::vector<uint8_t> Scheduler::complete_decode(const StepPlan& plan, const int32_t* tokens, const float* logprobs) {
   if (plan.kind != StepPlan::Decode) throw std::logic_error("complete_decode: not a decode plan");
+  std::vector<uint8_t> applied(plan.seq_ids.size(), 0);
   std::vector<int> touched;
-  size_t row = 0;
-  for (size_t gi = 0; gi < plan.group_first.size(); ++gi) {
-    const int gid = plan.request_ids[plan.group_first[gi]];
-    Group& g = groups_.at(gid);
-    touched.push_back(gid);
-    for (auto& c : g.chains) {
-      if (c.done) continue;
-      if (row >= plan.seq_ids.size() || plan.seq_ids[row] != c.seq)
-        throw std::logic_error("complete_decode: plan does not match scheduler state");
-      kv_->commit(c.seq, &c.last_token, 1);
-      const int32_t tok = tokens[row];
-      c.cum_logprob += logprobs ? logprobs[row] : 0.0;
-      c.out.push_back(tok);
-      c.last_token = tok;
-      FinishReason why;
-      if (is_stop(g, tok, &why)) finish_chain(g, c, why);
-      else if (static_cast<int>(c.out.size()) >= g.p.max_new_tokens) finish_chain(g, c, FinishReason::Length);
-      ++row;
+  auto apply = [&](Group& g, Chain& c, size_t row) {
+    kv_->commit(c.seq, &c.last_token, 1);
+    const int32_t tok = tokens[row];
+    c.cum_logprob += logprobs ? logprobs[row] : 0.0;
+    c.out.push_back(tok);
+    c.last_token = tok;
+    FinishReason why;
+    if (is_stop(g, tok, &why)) finish_chain(g, c, why);
+    else if (static_cast<int>(c.out.size()) >= g.p.max_new_tokens) finish_chain(g, c, FinishReason::Length);
+  };
+  if (plan.ahead) {
+    // The plan was made while the step before it was still running: a chain which that step
+    // ended (stop token) has a row here whose result is dropped, and its group may be gone.
+    for (size_t row = 0; row < plan.seq_ids.size(); ++row) {
+      const int gid = plan.request_ids[row];
+      auto it = groups_.find(gid);
+      if (it == groups_.end()) continue;
+      Group& g = it->second;
+      for (auto& c : g.chains) {
+        if (c.done || c.seq != plan.seq_ids[row]) continue;
+        apply(g, c, row);
+        applied[row] = 1;
+        if (touched.empty() || touched.back() != gid) touched.push_back(gid);
+        break;
+      }
+    }
+  } else {
+    size_t row = 0;
+    for (size_t gi = 0; gi < plan.group_first.size(); ++gi) {
+      const int gid = plan.request_ids[plan.group_first[gi]];
+      Group& g = groups_.at(gid);
+      touched.push_back(gid);
+      for (auto& c : g.chains) {
+        if (c.done) continue;
+        if (row >= plan.seq_ids.size() || plan.seq_ids[row] != c.seq)
+          throw std::logic_error("complete_decode: plan does not match scheduler state");
+        apply(g, c, row);
+        applied[row] = 1;
+        ++row;
+      }
     }
   }
   for (int gid : touched) maybe_retire(gid);
+  return applied;
 }
 
 void Scheduler::abort_request(int request_id) {

@@ -110,6 +110,12 @@ struct StepPlan {
   std::vector<int32_t> step_index;     // [B] how many tokens this chain has generated so far
   std::vector<uint64_t> seeds;         // [B] per-chain RNG stream id
 
+  // A decode step planned while the step before it was still in flight (Scheduler::schedule_ahead):
+  // token_ids are placeholders, src_rows[b] is the row of that earlier step whose sampled token
+  // is row b's input.
+  bool ahead = false;
+  std::vector<int32_t> src_rows;       // [B] (ahead plans only)
+
   // Copy-on-write block copies that must run before this step's KV writes.
   std::vector<int32_t> copy_src, copy_dst;
 };
@@ -123,6 +129,13 @@ class Scheduler {
   void abort_request(int request_id);
 
   StepPlan schedule();
+  // The decode step that follows `inflight` (a decode plan that has been launched and not yet
+  // completed), planned without its results: every chain is assumed to go on unless it reaches
+  // max_new_tokens in the step in flight. Returns an Idle plan when there is no basis for that
+  // (prompts waiting or being prefilled, a mixed step in flight, no block for a chain); the
+  // caller then completes the step in flight and calls schedule(). At most one step may be in
+  // flight when this is called, and complete_decode must be given the plans in launch order.
+  StepPlan schedule_ahead(const StepPlan& inflight);
   void set_mix_decode(bool on) { cfg_.mix_decode = on; }
   bool mix_decode() const { return cfg_.mix_decode; }
 
@@ -143,8 +156,10 @@ class Scheduler {
   };
   std::vector<SampleSlot> prefill_sample_layout(const StepPlan& plan) const;
 
-  // Decode bookkeeping: one sampled token (+ its log-prob) per row of the plan.
-  void complete_decode(const StepPlan& plan, const int32_t* tokens, const float* logprobs);
+  // Decode bookkeeping: one sampled token (+ its log-prob) per row of the plan. Returns, per
+  // row, whether the token was taken (always, except for rows of an `ahead` plan whose chain
+  // the step before it had already ended).
+  std::vector<uint8_t> complete_decode(const StepPlan& plan, const int32_t* tokens, const float* logprobs);
 
   std::vector<FinishedRequest> take_finished();
   bool has_work() const;
@@ -185,6 +200,7 @@ class Scheduler {
   // Makes room for one more token of every live chain of the running groups; preempts from
   // the youngest running group backwards when the pool is exhausted.
   void ensure_decode_capacity();
+  bool build_decode_plan(StepPlan& plan, const std::unordered_map<int, int>* prev_rows);
   void preempt(int gid);
   void finish_chain(Group& g, Chain& c, FinishReason r);
   void maybe_retire(int gid);

@@ -8,13 +8,20 @@ namespace {
 
 constexpr int kMaxChunksPerLane = 16;  // rows up to 16*64*8 = 8192 elements stay in registers
 
-// x[t,:] = E[ids[t],:]
+// x[t,:] = E[ids[t],:]. With a token feed, rows whose feed_rows[t] >= 0 take their id from
+// feed_tok[feed_rows[t]] instead: the token a row of the PREVIOUS decode step sampled, which is
+// still on the device when this step is launched ahead of that step's results.
 __global__ void embed_gather_kernel(const int32_t* __restrict__ ids, const bf16_t* __restrict__ E,
-                                    bf16_t* __restrict__ x, int T, int d, int vocab) {
+                                    bf16_t* __restrict__ x, int T, int d, int vocab,
+                                    const int32_t* __restrict__ feed_tok, const int32_t* __restrict__ feed_rows) {
   const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   if (row >= T) return;
   int id = ids[row];
+  if (feed_rows != nullptr) {
+    const int src = feed_rows[row];
+    if (src >= 0) id = feed_tok[src];
+  }
   id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
   const u32x4* src = reinterpret_cast<const u32x4*>(E + static_cast<size_t>(id) * d);
   u32x4* dst = reinterpret_cast<u32x4*>(x + static_cast<size_t>(row) * d);
@@ -218,11 +225,12 @@ __global__ __launch_bounds__(256) void l2_normalize_kernel(const float* __restri
 }  // namespace
 
 LC_EXPORT int lc_embed_gather(const void* ids, const void* E, void* x, int T, int d, int vocab,
-                              hipStream_t stream) {
+                              const void* feed_tok, const void* feed_rows, hipStream_t stream) {
   if (T <= 0) return 0;
-  if (d % 8) return -1;
+  if (d % 8 || ((feed_tok == nullptr) != (feed_rows == nullptr))) return -1;
   embed_gather_kernel<<<dim3((T + 3) / 4), dim3(256), 0, stream>>>(
-      static_cast<const int32_t*>(ids), static_cast<const bf16_t*>(E), static_cast<bf16_t*>(x), T, d, vocab);
+      static_cast<const int32_t*>(ids), static_cast<const bf16_t*>(E), static_cast<bf16_t*>(x), T, d, vocab,
+      static_cast<const int32_t*>(feed_tok), static_cast<const int32_t*>(feed_rows));
   LC_RETURN_LAST_ERROR();
 }
 

@@ -95,7 +95,7 @@ class _DecodeGraph:
         # numpy and shipped with a single H2D copy per step. Field order keeps the int64
         # seeds 8-byte aligned.
         fields = [("seeds", 2 * B), ("token_ids", B), ("positions", B), ("slot_mapping", B), ("ctx_lens", B),
-                  ("top_k", B), ("steps", B), ("kv_begin", B), ("temperature", B), ("top_p", B),
+                  ("top_k", B), ("steps", B), ("kv_begin", B), ("src_rows", B), ("temperature", B), ("top_p", B),
                   ("decision_ids", B * C), ("group_first", G), ("group_count", G), ("group_shared", G),
                   ("block_tables", B * MB)]
         total = sum(n for _, n in fields)
@@ -127,7 +127,9 @@ class _DecodeGraph:
             self.h[name] = hv
             off += n
         self.h["slot_mapping"][:] = -1
+        self.h["src_rows"][:] = -1
         self.h["top_p"][:] = 1.0
+        self.feed_set = False                 # the mirror's src_rows hold something other than -1
         self.nsplit = ops.choose_kv_splits(bucket, eng.model.hkv, ctx_class)
         # The shared-prefix pass scans each group's prompt once per kv head; a wave that walks
         # the whole prompt alone is a chain of dependent loads, so the prompt is cut into pieces of
@@ -140,30 +142,34 @@ class _DecodeGraph:
         prefix_waves = max(1, bucket * eng.model.hq // 8)
         hbm_pieces = max(1, min(-(-1024 // prefix_waves), ctx_class // 512))
         self.prefix_splits = max(1, min(4 * hbm_pieces, ctx_class // 128))
-        self.graph: Optional[int] = None      # key of the step's hipGraph in the engine's graph cache
-        self.pieces: Optional[List[tuple]] = None
+        # Two recorded forms of the step: without and with the gather of decision log-probs (a
+        # step needs it only when a row with decision targets can end in it). graph[v] is the key
+        # of the hipGraph in the engine's graph cache, outs[v] its static result tensors.
+        self.graph: Dict[bool, int] = {}
+        self.pieces: Dict[bool, List[tuple]] = {}
         self.lists = False
-        self.out_tokens = self.out_lps = self.out_dec = None
-        # pinned landing buffers of the step's results (numpy views of pinned arena memory; plain
-        # arrays on the CPU), and the row -> request map the host mirror was last filled for
-        if dev.type == "cuda":
-            self.res_tok = eng.rt.pinned.array((B,), np.int32)
-            self.res_lp = eng.rt.pinned.array((B,), np.float32)
-            self.res_dec = eng.rt.pinned.array((B, C), np.float32)
-            self.done = rt.Event()
-        else:
-            self.res_tok = np.zeros(B, dtype=np.int32)
-            self.res_lp = np.zeros(B, dtype=np.float32)
-            self.res_dec = np.zeros((B, C), dtype=np.float32)
-            self.done = None
+        self.outs: Dict[bool, tuple] = {}
+        # Results land in pinned buffers (numpy views of pinned arena memory). Two steps of an
+        # engine can be in flight (the second launched ahead of the first one's results), so
+        # there are two landing sets, used alternately.
+        self.land = [_Landing(eng, B, C), _Landing(eng, B, C)]
+        self.copied = rt.Event() if dev.type == "cuda" else None   # the mirror's last upload
+        self.copy_pending = False
         self.rows_key: Optional[np.ndarray] = None
-        self.any_decision = False
         self._graphs = eng.rt.graphs if dev.type == "cuda" else None
+
+    def begin_fill(self) -> None:
+        """The host mirror may be rewritten once the copy that last shipped it has read it."""
+        if self.copy_pending:
+            self.copied.synchronize()
+            self.copy_pending = False
 
     def upload(self) -> None:
         """The host mirror goes to the device block with one asynchronous copy on the step's stream."""
         if self.host is None:
             rt.copy_async(self.arena.data_ptr(), self.host_np.ctypes.data, self.host_np.nbytes, rt.H2D)
+            self.copied.record()
+            self.copy_pending = True
         else:
             self.arena.copy_(self.host)
 
@@ -172,29 +178,40 @@ class _DecodeGraph:
             is_prefill=False, block_tables=self.block_tables, ctx_lens=self.ctx_lens, nsplit=self.nsplit,
             groups=(self.group_first, self.group_count, self.group_shared) if self.with_prefix else None,
             kv_begin=self.kv_begin if self.with_prefix else None,
-            max_group_rows=eng.max_group_rows if self.with_prefix else 0, prefix_splits=self.prefix_splits)
+            max_group_rows=eng.max_group_rows if self.with_prefix else 0, prefix_splits=self.prefix_splits,
+            token_feed=(eng.last_tokens, self.src_rows))
 
-    def run_body(self, eng: "Engine"):
+    def run_body(self, eng: "Engine", with_dec: bool = True):
+        """One decode step over the static buffers. The sampled tokens go to the engine's
+        ``last_tokens`` (row b of the step at index b), where the next step can pick them up on
+        the device (rows of the mirror's ``src_rows`` that are >= 0)."""
         hidden = eng.model.forward(self.token_ids, self.positions, self.slot_mapping, self.meta(eng), eng.kv)
         logits = eng.model.logits(hidden)
-        tok, lp = ops.sample(logits, self.temperature, self.top_p, self.top_k, self.seeds, self.steps)
-        dec = ops.logprob_gather(logits, self.decision_ids)
+        tok, lp = ops.sample(logits, self.temperature, self.top_p, self.top_k, self.seeds, self.steps,
+                             out_tok=eng.last_tokens)
+        dec = ops.logprob_gather(logits, self.decision_ids) if with_dec else None
         return tok, lp, dec
 
-    def capture(self, eng: "Engine") -> None:
+    def ready(self, eng: "Engine", with_dec: bool) -> bool:
+        """Whether this step form can be launched without recording anything first."""
+        if not (eng.use_graphs or eng.piecewise) or not eng.model.decode_capturable(self.bucket):
+            return True
+        return with_dec in self.graph or with_dec in self.pieces
+
+    def capture(self, eng: "Engine", with_dec: bool = True) -> None:
         """Records the step into the engine's graph cache (runtime.GraphCache: thread-local stream
         capture, so HIP calls made meanwhile by other threads -- RCCL's watchdog, the HTTP front
         end, another engine's loopback rank -- do not invalidate it; tensors allocated while
         recording come from the cache's private pool and keep their addresses)."""
-        self.run_body(eng)                          # warm-up: allocator, lazy init, peer channels
+        self.run_body(eng, with_dec)                # warm-up: allocator, lazy init, peer channels
         torch.cuda.synchronize()
         key = eng.rt.new_key()
         with eng._capture_stream():
             with self._graphs.capture(key):
-                self.out_tokens, self.out_lps, self.out_dec = self.run_body(eng)
-        self.graph = key
+                self.outs[with_dec] = self.run_body(eng, with_dec)
+        self.graph[with_dec] = key
 
-    def capture_piecewise(self, eng: "Engine") -> None:
+    def capture_piecewise(self, eng: "Engine", with_dec: bool = True) -> None:
         """Tensor-parallel decode step as a chain of hipGraphs cut at the collectives: every
         stretch of kernels between two all-reduces (and up to the logits all-gather) is one
         graph, the collectives themselves are issued eagerly between the replays. A step of an
@@ -205,7 +222,7 @@ class _DecodeGraph:
         s = torch.cuda.Stream(device=eng.device)
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):
-            self.run_body(eng)                      # warm-up: allocator, lazy init, RCCL channels
+            self.run_body(eng, with_dec)            # warm-up: allocator, lazy init, RCCL channels
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
         pieces: List[tuple] = []
@@ -258,7 +275,7 @@ class _DecodeGraph:
         try:
             with torch.cuda.stream(s):
                 begin()
-                self.out_tokens, self.out_lps, self.out_dec = self.run_body(eng)
+                self.outs[with_dec] = self.run_body(eng, with_dec)
                 end()
         except BaseException as e:
             if cur[0] is not None:          # never leave a stream capture open behind an error
@@ -272,9 +289,9 @@ class _DecodeGraph:
             model.comm = inner
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
-        self.pieces = pieces
+        self.pieces[with_dec] = pieces
 
-    def capture_launch_lists(self, eng: "Engine") -> None:
+    def capture_launch_lists(self, eng: "Engine", with_dec: bool = True) -> None:
         """Same cut as capture_piecewise, but the stretches between collectives are kept as
         recorded launch lists (kernel entry point + argument tuple) instead of hipGraphs: a
         small hipGraph costs tens of microseconds to launch, more than the handful of kernels
@@ -288,7 +305,7 @@ class _DecodeGraph:
 
         model = eng.model
         inner = model.comm
-        self.run_body(eng)                          # warm-up
+        self.run_body(eng, with_dec)                # warm-up
         pieces: List[tuple] = []
         keep: List[torch.Tensor] = []
         cur = [_hip.start_recording()]
@@ -327,38 +344,54 @@ class _DecodeGraph:
         alloc_hook = _KeepAlive(keep)
         try:
             with alloc_hook:
-                self.out_tokens, self.out_lps, self.out_dec = self.run_body(eng)
+                self.outs[with_dec] = self.run_body(eng, with_dec)
             pieces.append((cur[0], None))
         finally:
             _hip.stop_recording()
             model.comm = inner
-        self._keep = keep
-        self.pieces = pieces
+        self._keep = getattr(self, "_keep", []) + keep
+        self.pieces[with_dec] = pieces
         self.lists = True
-        want = (self.out_tokens.clone(), self.out_lps.clone())
-        self.replay()
-        if not (torch.equal(want[0], self.out_tokens) and torch.allclose(want[1], self.out_lps, atol=1e-4)):
-            self.pieces, self.lists = None, False
+        out_tokens, out_lps, _ = self.outs[with_dec]
+        want = (out_tokens.clone(), out_lps.clone())
+        self.replay(with_dec)
+        if not (torch.equal(want[0], out_tokens) and torch.allclose(want[1], out_lps, atol=1e-4)):
+            del self.pieces[with_dec]
+            self.lists = bool(self.pieces)
             raise RuntimeError("recorded decode step does not reproduce the eager step")
 
-    def replay(self) -> None:
-        if self.graph is not None:
-            self._graphs.launch(self.graph)
+    def replay(self, with_dec: bool = True) -> None:
+        if with_dec in self.graph:
+            self._graphs.launch(self.graph[with_dec])
             return
         if self.lists:
             from ..ops.hip import replay as replay_list
 
-            for cmds, coll in self.pieces:
+            for cmds, coll in self.pieces[with_dec]:
                 if cmds is not None:
                     replay_list(cmds)
                 else:
                     coll()
             return
-        for key, coll in self.pieces:
+        for key, coll in self.pieces[with_dec]:
             if key is not None:
                 self._graphs.launch(key)
             else:
                 coll()
+
+
+class _Landing:
+    """Where the results of one decode step arrive on the host, and the event that says they have."""
+
+    def __init__(self, eng: "Engine", B: int, C: int) -> None:
+        if eng.device.type == "cuda":
+            self.tok = eng.rt.pinned.array((B,), np.int32)
+            self.lp = eng.rt.pinned.array((B,), np.float32)
+            self.dec = eng.rt.pinned.array((B, C), np.float32)
+            self.done = rt.Event()
+        else:
+            self.tok = self.lp = self.dec = None
+            self.done = None
 
 
 class _StepStaging:
@@ -434,7 +467,7 @@ class Engine:
                  kv_fraction: float = 0.6, enable_prefix_cache: bool = True, use_graphs: Optional[bool] = None,
                  graph_buckets: Sequence[int] = (1, 2, 4, 8, 16, 32, 64, 128, 256, 512), max_decision: int = 8,
                  max_group_rows: int = 16, name: str = "engine", mix_decode: bool = True,
-                 optimistic_admission: bool = False) -> None:
+                 optimistic_admission: bool = False, pipeline_decode: Optional[bool] = None) -> None:
         self.model, self.device, self.name = model, model.device, name
         cfg = model.cfg
         self.block_size = block_size
@@ -512,7 +545,27 @@ class Engine:
         # on the default stream, one engine at a time, and results must not change.
         self.stream = self.rt.stream.torch if (self.rt is not None and self.rt.stream is not None) else None
         self._side: Optional[rt.Stream] = None          # capture stream of the serialised debug mode
-        self._step_done = rt.Event() if self.rt is not None else None
+        # Two steps can be in flight (see ``pipeline_decode``): their events alternate.
+        self._step_events = [rt.Event(), rt.Event()] if self.rt is not None else None
+        self._step_no = 0
+        # Decode steps run ahead of their predecessor's results: while step N is on the GPU the
+        # host plans step N + 1 (Scheduler.schedule_ahead), ships its inputs and launches it; the
+        # tokens step N samples reach step N + 1 on the device (``last_tokens``), and the host
+        # reads them one step late. What the GPU would otherwise wait for between two steps
+        # (event wake-up, bookkeeping, scheduling, packing, the graph launch: ~0.3 ms against a
+        # 5-8 ms step) is hidden. A chain that a stop token ends in step N still has a row in
+        # step N + 1; that row's result is dropped.
+        if pipeline_decode is None:
+            pipeline_decode = os.environ.get("CONSENSUS_PIPELINE_DECODE", "1") == "1"
+        self.pipeline_decode = bool(pipeline_decode)
+        self._ahead = None          # (plan, token) of a step launched by end_step for the next begin_step
+        rows_cap = max_batch_seqs              # no decode step (bucket padding included) has more rows
+        if self.rt is not None:
+            self.last_tokens = self.rt.small.tensor((rows_cap,), torch.int32)
+            self.last_tokens.zero_()
+        else:
+            self.last_tokens = torch.zeros(rows_cap, dtype=torch.int32, device=self.device)
+        self._dec_cache = None      # (request ids, rows with decision targets) of the newest decode batch
         self._staging = _StepStaging(self.device)
         if self.stream is not None:
             self.stream.wait_stream(torch.cuda.current_stream(self.device))   # weights were written there
@@ -560,6 +613,8 @@ class Engine:
         self.kvm.drop_cache()
         self._reqs.clear()
         self._last_dec = None
+        self._ahead = None
+        self._dec_cache = None
         for g in self._graphs.values():
             g.rows_key = None
         self.metrics.inc("requests.aborted", len(rids))
@@ -597,13 +652,19 @@ class Engine:
 
     def plan_step(self):
         """Asks the scheduler for the next step without launching it (None when idle). The plan
-        may be held back by a driver and launched later with ``launch_step``."""
+        may be held back by a driver and launched later with ``launch_step``. When the previous
+        ``end_step`` already launched the next decode step, that step's plan is returned."""
+        if self._ahead is not None:
+            return self._ahead[0]
         t0 = time.perf_counter()
         plan = self.sched.schedule()
         self.metrics.inc("host.schedule_seconds", time.perf_counter() - t0)
         return None if plan.kind == PK.Idle else plan
 
     def launch_step(self, plan):
+        if self._ahead is not None and plan is self._ahead[0]:
+            token, self._ahead = self._ahead[1], None
+            return token
         t0 = time.perf_counter()
         with self._on_stream():
             if len(plan.copy_src):
@@ -617,8 +678,28 @@ class Engine:
                     state = self._decode_launch(plan)
             done = None
             if self.stream is not None:
-                done = self._step_done.record()     # one step of an engine is in flight at a time
+                done = self._step_events[self._step_no & 1].record()
+            self._step_no += 1
         return plan, state, t0, done
+
+    def _launch_ahead(self, plan) -> None:
+        """While the decode step ``plan`` is on the GPU: plans and launches the step after it."""
+        t0 = time.perf_counter()
+        nxt = self.sched.schedule_ahead(plan)
+        self.metrics.inc("host.schedule_seconds", time.perf_counter() - t0)
+        if nxt.kind != PK.Decode:
+            return
+        if not self._decode_ready(nxt):
+            # The step's graph would have to be recorded first, and recording runs the step once
+            # for real (its sampler would overwrite the tokens the recorded step is to read):
+            # this step takes the ordinary path. Nothing is lost but the overlap: the blocks
+            # reserved for it are the ones the ordinary plan reserves again.
+            if len(nxt.copy_src):
+                with self._on_stream():
+                    self.kv.copy_blocks(self._dev(nxt.copy_src), self._dev(nxt.copy_dst))
+            return
+        self._ahead = (nxt, self.launch_step(nxt))
+        self.metrics.inc("decode.ahead_steps")
 
     @staticmethod
     def step_done(token) -> bool:
@@ -628,6 +709,8 @@ class Engine:
     def end_step(self, token) -> None:
         """Waits for the step started by ``begin_step`` and does its bookkeeping."""
         plan, state, t0, _ = token
+        if self.pipeline_decode and plan.kind == PK.Decode and self._ahead is None:
+            self._launch_ahead(plan)
         with self._on_stream():
             if plan.kind == PK.Prefill:
                 self._prefill_finish(plan, state)
@@ -811,8 +894,8 @@ class Engine:
                 return b
         return B
 
-    def _decode_launch(self, plan):
-        t_fill = time.perf_counter()
+    def _decode_key(self, plan):
+        """(bucket, shared-prefix pass, context class) of a decode plan: which recorded step runs it."""
         B = len(plan.seq_ids)
         gshared = plan.group_shared_blocks
         gcount = plan.group_count
@@ -826,14 +909,64 @@ class Engine:
         bucket = self._bucket(B) if (self.use_graphs or self.piecewise) else B
         max_ctx = int(plan.context_lens.max())
         ctx_class = next((c for c in self.ctx_classes if c >= max_ctx), self.ctx_classes[-1])
-        key = (bucket, with_prefix, ctx_class)
+        return (bucket, with_prefix, ctx_class), gshared, gcount
+
+    def _decision_rows(self, req_ids: np.ndarray):
+        """Rows of a decode batch whose request has decision targets, with what the batch's rows
+        need to know about ending: (row indices, max_new_tokens per row, whether any such row can
+        be ended by a stop token). Cached while the batch keeps its rows."""
+        c = self._dec_cache
+        if c is not None and c[0].shape == req_ids.shape and np.array_equal(c[0], req_ids):
+            return c[1], c[2], c[3]
+        rows, max_new, can_stop = [], np.zeros(len(req_ids), dtype=np.int32), False
+        seen: Dict[int, tuple] = {}
+        for b, rid in enumerate(req_ids.tolist()):
+            e = seen.get(rid)
+            if e is None:
+                p = self.sched.params_of(rid)
+                e = seen[rid] = (bool(self._reqs[rid].decision_ids), p.max_new_tokens,
+                                 (not p.ignore_eos and p.eos_id >= 0) or bool(p.stop_ids))
+            max_new[b] = e[1]
+            if e[0]:
+                rows.append(b)
+                can_stop = can_stop or e[2]
+        rows = np.asarray(rows, dtype=np.int64)
+        self._dec_cache = (np.array(req_ids, copy=True), rows, max_new, can_stop)
+        return rows, max_new, can_stop
+
+    def _needs_decisions(self, plan) -> bool:
+        """A chain's decision log-probs are those of its LAST step, so the gather runs only in a
+        step that can be some such chain's last: one that a stop token may end, or the one in
+        which it reaches max_new_tokens."""
+        rows, max_new, can_stop = self._decision_rows(plan.request_ids)
+        if not len(rows):
+            return False
+        if can_stop:
+            return True
+        return bool((plan.step_index[rows] + 1 >= max_new[rows]).any())
+
+    def _decode_ready(self, plan) -> bool:
+        """Whether a decode plan can be launched without recording a graph first."""
+        if not (self.use_graphs or self.piecewise):
+            return True
+        key, _, _ = self._decode_key(plan)
+        g = self._graphs.get(key)
+        return g is not None and g.ready(self, self._needs_decisions(plan))
+
+    def _decode_launch(self, plan):
+        t_fill = time.perf_counter()
+        B = len(plan.seq_ids)
+        key, gshared, gcount = self._decode_key(plan)
+        bucket, with_prefix, ctx_class = key
         g = self._graphs.get(key)
         if g is None:
             g = _DecodeGraph(self, bucket, with_prefix, ctx_class)
             if not self.use_graphs:
                 g.nsplit = 1 if self.device.type != "cuda" else g.nsplit
             self._graphs[key] = g
+        with_dec = self._needs_decisions(plan)
         # ---- fill the pinned host mirror, then one H2D copy ----
+        g.begin_fill()
         h = g.h
 
         def put(name: str, a: np.ndarray, fill=0):
@@ -847,6 +980,13 @@ class Engine:
         put("positions", plan.positions)
         put("slot_mapping", plan.slot_mapping, -1)
         put("ctx_lens", plan.context_lens)
+        if plan.ahead:
+            # the input tokens are still being sampled: row b reads last_tokens[src_rows[b]]
+            put("src_rows", plan.src_rows, -1)
+            g.feed_set = True
+        elif g.feed_set:
+            h["src_rows"][:] = -1
+            g.feed_set = False
         bt = plan.block_tables
         h["block_tables"][:B, : bt.shape[1]] = np.maximum(bt, 0)
         req_ids = plan.request_ids
@@ -854,7 +994,6 @@ class Engine:
         # batch usually keeps its rows for many steps, so the host mirror is refilled only then.
         if g.rows_key is None or g.rows_key.shape[0] != B or not np.array_equal(g.rows_key, req_ids):
             cache: Dict[int, tuple] = {}
-            g.any_decision = False
             for b in range(B):
                 rid = int(req_ids[b])
                 e = cache.get(rid)
@@ -865,14 +1004,12 @@ class Engine:
                     cache[rid] = e
                 h["temperature"][b], h["top_p"][b], h["top_k"][b] = e[0], e[1], e[2]
                 if e[3]:
-                    g.any_decision = True
                     h["decision_ids"][b, : len(e[3])] = e[3]
             if B < bucket:
                 h["temperature"][B:] = 0.0
                 h["top_p"][B:] = 1.0
                 h["top_k"][B:] = 0
             g.rows_key = np.array(req_ids, copy=True)
-        any_decision = g.any_decision
         put("seeds", plan.seeds.astype(np.int64))
         put("steps", plan.step_index)
         if with_prefix:
@@ -897,50 +1034,62 @@ class Engine:
         self.metrics.inc("host.decode_fill_seconds", t_launch - t_fill)
         # ---- run ----
         if (self.use_graphs or self.piecewise) and self.model.decode_capturable(bucket):
-            if g.graph is None and g.pieces is None:
+            if not g.ready(self, with_dec):
+                if plan.ahead:
+                    raise RuntimeError("a decode step launched ahead must not record its graph")
+                t_cap = time.perf_counter()
                 if self.use_graphs:
-                    g.capture(self)
+                    g.capture(self, with_dec)
                 elif self.piecewise == "graphs":
-                    g.capture_piecewise(self)
+                    g.capture_piecewise(self, with_dec)
                 else:
-                    g.capture_launch_lists(self)
-            g.replay()
-            tok, lp, dl = g.out_tokens, g.out_lps, g.out_dec
+                    g.capture_launch_lists(self, with_dec)
+                self.metrics.inc("decode.graph_captures")
+                self.metrics.inc("decode.graph_capture_seconds", time.perf_counter() - t_cap)
+            g.replay(with_dec)
+            tok, lp, dl = g.outs[with_dec]
         else:
-            tok, lp, dl = g.run_body(self)
+            tok, lp, dl = g.run_body(self, with_dec)
         # Results come back through pinned buffers: the copies are queued right behind the step,
         # and the host later waits once instead of doing three blocking reads.
+        land = g.land[self._step_no & 1]
         if self.device.type == "cuda":
-            rt.copy_async(g.res_tok.ctypes.data, tok.data_ptr(), 4 * tok.numel(), rt.D2H)
-            rt.copy_async(g.res_lp.ctypes.data, lp.data_ptr(), 4 * lp.numel(), rt.D2H)
-            if any_decision:
-                rt.copy_async(g.res_dec.ctypes.data, dl.data_ptr(), 4 * dl.numel(), rt.D2H)
-            done = g.done.record()
+            rt.copy_async(land.tok.ctypes.data, tok.data_ptr(), 4 * bucket, rt.D2H)
+            rt.copy_async(land.lp.ctypes.data, lp.data_ptr(), 4 * lp.numel(), rt.D2H)
+            if with_dec:
+                rt.copy_async(land.dec.ctypes.data, dl.data_ptr(), 4 * dl.numel(), rt.D2H)
+            land.done.record()
             self.metrics.inc("host.decode_launch_seconds", time.perf_counter() - t_launch)
-            return g, done, any_decision
-        g.res_tok, g.res_lp, g.res_dec = tok.numpy(), lp.numpy(), dl.numpy()
-        return g, None, any_decision
+            return g, land, with_dec
+        # the host copies are taken now: the next step overwrites last_tokens
+        land.tok, land.lp = tok[:bucket].numpy().copy(), lp.numpy().copy()
+        land.dec = dl.numpy().copy() if with_dec else None
+        return g, land, with_dec
 
     def _decode_finish(self, plan, state) -> None:
-        g, done, any_decision = state
-        if done is not None:
+        g, land, with_dec = state
+        if land.done is not None:
             t_wait = time.perf_counter()
-            done.synchronize()
+            land.done.synchronize()
             # time the host spent blocked on the GPU; decode.seconds minus this is host work
             self.metrics.inc("decode.wait_seconds", time.perf_counter() - t_wait)
         t_fin = time.perf_counter()
         B = len(plan.seq_ids)
-        tok_h = g.res_tok[:B].astype(np.int32)
-        lp_h = g.res_lp[:B].astype(np.float32)
-        if any_decision:
+        tok_h = land.tok[:B].astype(np.int32)
+        lp_h = land.lp[:B].astype(np.float32)
+        taken = self.sched.complete_decode(plan, tok_h, lp_h)
+        if with_dec:
             # A chain's decision log-probs are those of its LAST step. Keeping the newest row
             # block and resolving rows only when they leave the batch avoids a Python loop
-            # over every row at every step.
-            cur = (np.array(plan.request_ids, copy=True), np.array(plan.seeds, copy=True),
-                   g.res_dec[:B].copy())
+            # over every row at every step. Rows of a step launched ahead whose chain had
+            # already ended (``taken`` 0) carry nothing.
+            rids, seeds, vals = plan.request_ids, plan.seeds, land.dec[:B]
+            if plan.ahead and not taken.all():
+                live = np.nonzero(taken)[0]
+                rids, seeds, vals = rids[live], seeds[live], vals[live]
+            cur = (np.array(rids, copy=True), np.array(seeds, copy=True), np.array(vals, copy=True))
             self._flush_decisions(keep=cur)
             self._last_dec = cur
-        self.sched.complete_decode(plan, tok_h, lp_h)
         self.metrics.inc("host.decode_finish_seconds", time.perf_counter() - t_fin)
 
     def _flush_decisions(self, keep=None, only_request: Optional[int] = None) -> None:

@@ -42,6 +42,8 @@ class AttnMeta:
     # above; the remaining rows are one-token decode sequences described by ``riders``.
     riders: Optional["AttnMeta"] = None
     prefill_tokens: int = 0
+    # Decode steps launched ahead of the previous step's results: (tokens, rows), see ops.embed.
+    token_feed: Optional[Tuple[torch.Tensor, torch.Tensor]] = None
 
 
 @dataclass
@@ -243,7 +245,7 @@ class TransformerModel:
                 meta: AttnMeta, kv: KVCache) -> torch.Tensor:
         """Returns the final-norm hidden states [T, d] for the step's tokens."""
         c = self.cfg
-        h = ops.embed(token_ids, self.embed)
+        h = ops.embed(token_ids, self.embed, meta.token_feed)
         delta = None
         for i, L in enumerate(self.layers):
             x = self._reduce_norm(h, delta, L.ln1)

@@ -306,13 +306,20 @@ def linear(x: torch.Tensor, w: LinearWeight, out_f32: bool = False, defer_reduce
 
 
 # ---------------------------------------------------------------------------- elementwise
-def embed(ids: torch.Tensor, E: torch.Tensor) -> torch.Tensor:
+def embed(ids: torch.Tensor, E: torch.Tensor, feed: Optional[Tuple[torch.Tensor, torch.Tensor]] = None) -> torch.Tensor:
+    """x[t] = E[ids[t]]. ``feed`` = (tokens int32 [*], rows int32 [T]): row t with rows[t] >= 0
+    takes the id tokens[rows[t]] instead (the token sampled by a row of the previous decode step,
+    read on the device by a step that was launched before that step's results came back)."""
     if not ids.is_cuda:
+        if feed is not None:
+            tok, rows = feed
+            ids = torch.where(rows >= 0, tok[rows.clamp_min(0).long()].to(ids.dtype), ids)
         return ref.embed(ids, E)
     h = _hip()
     T, d = ids.numel(), E.shape[1]
     x = torch.empty(T, d, dtype=E.dtype, device=E.device)
-    h.call("lc_embed_gather", ids.data_ptr(), E.data_ptr(), x.data_ptr(), T, d, E.shape[0])
+    h.call("lc_embed_gather", ids.data_ptr(), E.data_ptr(), x.data_ptr(), T, d, E.shape[0],
+           feed[0].data_ptr() if feed is not None else None, feed[1].data_ptr() if feed is not None else None)
     return x
 
 
@@ -505,14 +512,19 @@ def attn_decode(qkv, k_cache, vt_cache, block_tables, ctx_lens, Hq, Hkv, Dh, sca
 
 
 # ---------------------------------------------------------------------------- sampling
-def sample(logits, temperature, top_p, top_k, seeds, steps, row_index=None):
+def sample(logits, temperature, top_p, top_k, seeds, steps, row_index=None, out_tok: Optional[torch.Tensor] = None):
     """logits fp32 [*, V]; per-row params are device tensors (float32/float32/int32/int64/int32).
-    Returns (tokens int32 [R], logprobs float32 [R])."""
+    Returns (tokens int32 [R], logprobs float32 [R]); the tokens are written into ``out_tok``
+    (int32, at least R long) when given."""
     if not logits.is_cuda:
-        return ref.sample(logits, temperature, top_p, top_k, seeds, steps, row_index)
+        tok, lp = ref.sample(logits, temperature, top_p, top_k, seeds, steps, row_index)
+        if out_tok is not None:
+            out_tok[: tok.numel()].copy_(tok)
+            tok = out_tok[: tok.numel()]
+        return tok, lp
     h = _hip()
     R = temperature.numel()
-    tok = torch.empty(R, dtype=torch.int32, device=logits.device)
+    tok = out_tok[:R] if out_tok is not None else torch.empty(R, dtype=torch.int32, device=logits.device)
     lp = torch.empty(R, dtype=torch.float32, device=logits.device)
     h.call("lc_sample", logits.data_ptr(), logits.shape[1], logits.stride(0), h.ptr(row_index),
            temperature.data_ptr(), h.ptr(top_p), h.ptr(top_k), seeds.data_ptr(), h.ptr(steps), tok.data_ptr(),

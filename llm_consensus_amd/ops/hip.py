@@ -19,7 +19,7 @@ from .._native import kernels
 _P, _I, _F, _L = c_void_p, c_int, c_float, c_longlong
 
 _SIGNATURES = {
-    "lc_embed_gather": [_P, _P, _P, _I, _I, _I, _P],
+    "lc_embed_gather": [_P, _P, _P, _I, _I, _I, _P, _P, _P],
     "lc_rmsnorm": [_P, _P, _P, _P, _I, _I, _F, _P, _I, _P],
     "lc_swiglu": [_P, _P, _I, _I, _P],
     "lc_add": [_P, _P, _P, _L, _P],

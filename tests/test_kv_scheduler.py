@@ -296,3 +296,104 @@ def run_to_completion_from(sched, plan):
     fin = sched.take_finished()
     more, steps = run_to_completion(sched)
     return fin + more, steps
+
+
+def test_optimistic_mixed_steps_with_forked_chains_crossing_a_block_boundary():
+    """16 blocks of 4 tokens; a running request with four chains and a 20-token prompt admitted at
+    step 6, with optimistic admission AND mixed steps: when all four chains cross a block
+    boundary in the step that prefills the newcomer there is no running victim, so the newcomer
+    itself (admitted moments ago) has to give its blocks back; the step must not throw."""
+    outs = {}
+    for mix in (False, True):
+        kv = core.KVManager(16, 4, False)
+        cfg = core.SchedulerConfig()
+        cfg.max_batch_seqs, cfg.max_prefill_tokens = 16, 64
+        cfg.optimistic_admission, cfg.mix_decode = True, mix
+        sched = core.Scheduler(kv, cfg)
+        p = core.SamplingParams(); p.max_new_tokens = 8
+        first = sched.add_request(core.RequestKind.Generate, toks(6), 4, p)
+        fin, late = [], None
+        for step in range(200):
+            if step == 6:
+                p2 = core.SamplingParams(); p2.max_new_tokens = 4
+                late = sched.add_request(core.RequestKind.Generate, toks(20, 100), 1, p2)
+            plan = sched.schedule()
+            if plan.kind == core.StepPlan.Kind.Idle:
+                break
+            finish_step(sched, plan, vocab=1000)
+            fin += sched.take_finished()
+        assert sorted(f.request_id for f in fin) == [first, late], mix
+        outs[mix] = {f.request_id: [list(c.tokens) for c in f.chains] for f in fin}
+        assert kv.available_blocks() == 16
+    assert outs[False] == outs[True]
+
+
+def test_schedule_ahead_continues_a_decode_step_without_its_results():
+    """schedule_ahead plans step N + 1 while step N is in flight: same rows minus the chains
+    that end by length in step N, positions one further, src_rows naming the rows of step N,
+    and the tokens a fake model produces are the same as with one step at a time."""
+    def run(ahead: bool, eos=None):
+        kv = core.KVManager(64, 4, False)
+        cfg = core.SchedulerConfig()
+        cfg.max_batch_seqs, cfg.max_prefill_tokens = 16, 64
+        sched = core.Scheduler(kv, cfg)
+        reqs = []
+        for i, (n_new, n) in enumerate([(5, 1), (9, 2), (3, 1)]):
+            p = core.SamplingParams(); p.max_new_tokens = n_new
+            if eos is not None:
+                p.eos_id = eos
+            else:
+                p.ignore_eos = True
+            reqs.append(sched.add_request(core.RequestKind.Generate, toks(6 + i, 10 * i), n, p))
+        plan = sched.schedule()
+        assert plan.kind == core.StepPlan.Kind.Prefill
+        finish_step(sched, plan)
+        fin = sched.take_finished()
+        n_ahead = 0
+        plan = sched.schedule()
+        last_tok = None
+        while plan.kind != core.StepPlan.Kind.Idle:
+            assert plan.kind == core.StepPlan.Kind.Decode
+            toks_in = np.array(plan.token_ids)
+            if plan.ahead:
+                toks_in = last_tok[plan.src_rows]              # what the device-side feed does
+            out = ((toks_in + 1) % 50).astype(np.int32)
+            nxt = sched.schedule_ahead(plan) if ahead else None
+            taken = sched.complete_decode(plan, out, np.zeros(len(out), dtype=np.float32))
+            assert plan.ahead or taken.all()
+            last_tok = out
+            fin += sched.take_finished()
+            if nxt is not None and nxt.kind == core.StepPlan.Kind.Decode:
+                assert nxt.ahead and len(nxt.src_rows) == len(nxt.seq_ids)
+                assert (np.array(plan.seq_ids)[nxt.src_rows] == np.array(nxt.seq_ids)).all()
+                n_ahead += 1
+                plan = nxt
+            else:
+                plan = sched.schedule()
+        assert kv.available_blocks() == 64
+        return {f.request_id: [list(c.tokens) for c in f.chains] for f in fin}, n_ahead
+
+    base, _ = run(False)
+    piped, n_ahead = run(True)
+    assert piped == base and n_ahead >= 6
+    # stop tokens: a chain ended by one in step N still has a (dropped) row in step N + 1
+    base, _ = run(False, eos=21)
+    piped, n_ahead = run(True, eos=21)
+    assert piped == base and n_ahead >= 2
+    assert len(base[1][0]) < 9 and base[1][0][-1] == 21          # the stop token really cut a chain
+
+
+def test_schedule_ahead_refuses_when_prompts_wait():
+    kv = core.KVManager(64, 4, False)
+    cfg = core.SchedulerConfig()
+    cfg.max_batch_seqs, cfg.max_prefill_tokens = 16, 64
+    sched = core.Scheduler(kv, cfg)
+    p = core.SamplingParams(); p.max_new_tokens, p.ignore_eos = 6, True
+    sched.add_request(core.RequestKind.Generate, toks(5), 1, p)
+    finish_step(sched, sched.schedule())
+    plan = sched.schedule()
+    assert plan.kind == core.StepPlan.Kind.Decode
+    sched.add_request(core.RequestKind.Generate, toks(7, 30), 1, p)
+    assert sched.schedule_ahead(plan).kind == core.StepPlan.Kind.Idle
+    finish_step(sched, plan)
+    assert sched.schedule().kind == core.StepPlan.Kind.Prefill
