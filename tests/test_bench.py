@@ -27,9 +27,14 @@ def run_bench(args, env=None, timeout=300):
 
 
 def json_line(p):
-    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
-    assert len(lines) == 1, (p.stdout[-2000:], p.stderr[-2000:])
-    return json.loads(lines[0])
+    """The result is the LAST line; every line before it is the same record at an earlier point of
+    the run, marked provisional and growing section by section."""
+    lines = [json.loads(l) for l in p.stdout.splitlines() if l.startswith("{")]
+    assert lines, (p.stdout[-2000:], p.stderr[-2000:])
+    assert "provisional" not in lines[-1]
+    for earlier, later in zip(lines, lines[1:]):
+        assert "provisional" in earlier and set(earlier) - {"provisional"} <= set(later)
+    return lines[-1]
 
 
 def test_gpus_flag_launches_that_many_ranks_for_every_workload():

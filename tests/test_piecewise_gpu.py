@@ -52,7 +52,8 @@ def _run(piecewise: str, monkeypatch):
     rids = [eng.submit(pr, params=p, decision_ids=[3, 9]) for pr in PROMPTS]
     eng.run_until_done()
     outs = [eng.pop_result(r) for r in rids]
-    pieces = [g.pieces for g in eng._graphs.values() if g.pieces]
+    # one chain of pieces per recorded form of the step (with / without the decision gather)
+    pieces = [chain for g in eng._graphs.values() for chain in g.pieces.values()]
     return [o.token_ids[0] for o in outs], [o.decision_logprobs for o in outs], pieces, comm.calls
 
 
