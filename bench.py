@@ -575,6 +575,10 @@ def run_configured(ctx: Ctx, cfg, per_replica: int, prompt_len: int, steps: int,
                   **extra)
     if kept:
         sec["mean_member_calls"] = round(float(np.mean([r.member_calls for r in kept])), 2)
+    if hasattr(ens, "collectives"):
+        used = ens.collectives()
+        if used:
+            sec["collectives"] = used
     del ens, ask
     ctx.free()
     return sec
@@ -600,9 +604,11 @@ def _child_args(argv, letter: str, out_path: str):
 def run_isolated(ctx: Ctx, a, argv, letter: str, extra_args=(), pick=None):
     """Multi-GPU runs: a sharded workload (D: tensor-parallel judge, E: expert-parallel MoE) runs
     in child processes, one per rank, with a process group of their own and a time limit. Its
-    collectives go through peer-to-peer kernels over IPC-mapped memory; should that path fail or
-    stall on a machine (it then times out and flags an error instead of hanging), the section
-    is tried once more on RCCL collectives, and if that fails too the section reports the error.
+    collectives go through peer-to-peer kernels over IPC-mapped memory. A group whose first
+    exchange fails its self-check switches to RCCL inside the child (parallel/p2p.py); should
+    the child fail or stall all the same (a collective then times out and flags an error
+    instead of hanging), the section is tried once more on eagerly issued RCCL collectives, and
+    if that fails too the section reports the error.
     Either way the replica workloads measured before it keep their numbers and the line is
     printed. Children are new interpreters started as child processes; nothing is replaced."""
     import signal
@@ -610,7 +616,8 @@ def run_isolated(ctx: Ctx, a, argv, letter: str, extra_args=(), pick=None):
 
     lead = ctx.rank == 0
     errors = []
-    attempts = [("p2p kernels over IPC-mapped memory", {}), ("rccl", {"LC_P2P": "0"})]
+    # second attempt: the most conservative form, RCCL collectives issued eagerly
+    attempts = [("p2p kernels over IPC-mapped memory", {}), ("rccl", {"LC_P2P": "0", "LC_RCCL_CAPTURE": "0"})]
     if getattr(ctx, "p2p_failed", False):
         attempts = attempts[1:]                    # an earlier section already found that path unusable here
     for label, extra in attempts:
@@ -643,7 +650,7 @@ def run_isolated(ctx: Ctx, a, argv, letter: str, extra_args=(), pick=None):
             if lead:
                 full = json.loads(Path(path).read_text())
                 sec = pick(full) if pick else full[{"D": "judge_consensus", "E": "moe_medoid"}[letter]]
-                sec["collectives"] = label
+                sec.setdefault("collectives", label)
                 if errors:
                     sec["first_attempt"] = errors
             return ctx.comm.broadcast_object(sec, 0)

@@ -529,6 +529,12 @@ LC_EXPORT int lc_p2p_comm_error(void* comm) {
 
 LC_EXPORT long long lc_p2p_comm_capacity(void* comm) { return static_cast<CommState*>(comm)->reg.stage_bytes; }
 
+// How long the kernels launched from now on wait for a peer (the first-contact check of a new
+// group uses a few seconds; a serving group a limit that outlasts a peer's longest other step).
+LC_EXPORT void lc_p2p_comm_set_timeout(void* comm, double timeout_s) {
+  static_cast<CommState*>(comm)->timeout = static_cast<unsigned long long>(timeout_s * 1e8);
+}
+
 #define LC_P2P_BY_WORLD(KERNEL, ...)                                           \
   switch (c->world) {                                                          \
     case 2: KERNEL(2, __VA_ARGS__); break;                                     \

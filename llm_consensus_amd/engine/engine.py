@@ -521,7 +521,11 @@ class Engine:
             use_graphs = False          # debugging: every launch goes through the ops layer, eagerly
         use_graphs_arg = use_graphs
         if use_graphs is None:
-            use_graphs = capturable
+            # RCCL collectives are recorded too (thread-local capture mode), unless
+            # LC_RCCL_CAPTURE=0 asks for eager steps: this is where a group lands whose
+            # peer-to-peer collectives failed their first-contact check (parallel/p2p.py).
+            use_graphs = capturable or (bool(getattr(model.comm, "capturable_thread_local", False))
+                                        and os.environ.get("LC_RCCL_CAPTURE", "1") == "1")
         elif use_graphs and not capturable and self.device.type == "cuda" and \
                 not getattr(model.comm, "capturable_thread_local", False):
             raise ValueError(f"{name}: use_graphs=True needs a group communicator whose collectives can be recorded "

@@ -224,6 +224,23 @@ class DistributedEnsemble:
     def stats(self) -> Dict[str, Dict[str, float]]:
         return {n: b.stats() for n, b in self.backends.items()}
 
+    def collectives(self) -> Dict[str, str]:
+        """Which transport every sharded model's group ended up on (peer-to-peer kernels, or the
+        bootstrap communicator after a failed first-contact check, with the reason). Collective."""
+        mine = {}
+        for name, b in self.backends.items():
+            eng = getattr(b.local, "engine", None) if b.local is not None else None
+            comm = getattr(getattr(eng, "model", None), "comm", None)
+            if comm is not None and comm.world > 1:
+                what = getattr(comm, "collectives", type(comm).__name__)
+                why = getattr(comm, "fallback_reason", None)
+                mine[name] = what + (f" (peer-to-peer self-check failed: {why})" if why else "") + \
+                    (", decode steps recorded as hipGraphs" if eng.use_graphs else ", eager decode steps")
+        out: Dict[str, str] = {}
+        for part in self.comm.all_gather_object(mine):
+            out.update(part or {})
+        return out
+
 
 class LeaderEnsemble:
     """Front-end view of a DistributedEnsemble on rank 0: the REPL / HTTP server calls

@@ -238,7 +238,7 @@ def main() -> None:
         want_scores, want_toks, _ = run(TransformerModel.random_init(cfg, DEV, seed=6, std=0.05), True)
         tp = TransformerModel.random_init(cfg, DEV, seed=6, std=0.05, tp_rank=rank, tp_size=W, comm=comm)
         got_scores, got_toks, eng = run(tp, None)
-        assert eng.use_graphs and any(g.graph is not None for g in eng._graphs.values()), "TP decode was not captured"
+        assert eng.use_graphs and any(g.graph for g in eng._graphs.values()), "TP decode was not captured"
         assert np.allclose(got_scores, want_scores, atol=0.06), (got_scores, want_scores)
         toks = base.all_gather_object(list(got_toks))
         assert all(t == toks[0] for t in toks), "TP ranks sampled different tokens"
@@ -277,7 +277,7 @@ def main() -> None:
         for mode in ("a2a", "allreduce"):
             m = TransformerModel.random_init(mcfg, DEV, seed=5, std=0.08, comm=comm, ep_size=W, ep_mode=mode)
             got_scores, got_toks, eng = run_moe(m)
-            assert eng.use_graphs and any(g.graph is not None for g in eng._graphs.values()), mode
+            assert eng.use_graphs and any(g.graph for g in eng._graphs.values()), mode
             assert np.allclose(got_scores, want_scores, atol=0.06), (mode, got_scores, want_scores)
             toks = base.all_gather_object(list(got_toks))
             assert all(t == toks[0] for t in toks), mode

@@ -294,3 +294,41 @@ def test_only_fixed_capacity_ep_steps_are_graph_capturable():
     assert not a2a.decode_capturable(2 * EP_FIXED_MAX_ROWS // k + 2)
     ar = TransformerModel.random_init(cfg, torch.device("cpu"), seed=0, ep_size=2, ep_mode="allreduce")
     assert ar.decode_capturable(1 << 20)
+
+
+
+def test_group_comm_first_contact_agreement_on_loopback(monkeypatch):
+    """wrap_group_comm: when ONE rank's first-contact check of the peer-to-peer collectives fails,
+    every rank of the group lands on the bootstrap communicator with the same reason (the kernels
+    themselves need GPUs; tests/test_p2p_gpu.py runs them with injected faults)."""
+    from llm_consensus_amd.parallel import p2p
+    from llm_consensus_amd.parallel.comm import run_loopback
+
+    class FakeP2P:
+        closed = []
+
+        def __init__(self, base, device, stage_bytes):
+            self.base, self.rank, self.world, self._h = base, base.rank, base.world, 1
+
+        def self_check(self):
+            bad = "rank 1: timed out" if self.rank == 1 and FakeP2P.fail else None
+            if self.base.all_true(bad is None):
+                return None
+            return "; ".join(w for w in self.base.all_gather_object(bad) if w)
+
+        def close(self):
+            FakeP2P.closed.append(self.rank)
+
+    monkeypatch.setattr(p2p, "P2PComm", FakeP2P)
+    monkeypatch.setattr(p2p, "supported", lambda world, device: True)
+
+    def build(comm):
+        c = p2p.wrap_group_comm(comm, "cpu")
+        return type(c).__name__, getattr(c, "collectives", None), getattr(c, "fallback_reason", None)
+
+    FakeP2P.fail = False
+    assert all(r[0] == "FakeP2P" and r[1].startswith("p2p") for r in run_loopback(2, build))
+    FakeP2P.fail = True
+    out = run_loopback(2, build)
+    assert all(r[0] == "LoopbackComm" and r[2] == "rank 1: timed out" for r in out), out
+    assert sorted(FakeP2P.closed) == [0, 1]
