@@ -74,6 +74,17 @@ class Ensemble:
             instant("session.done", "ensemble", rounds=r.rounds, calls=r.member_calls, unanimous=r.unanimous,
                     latency_ms=round(r.latency_s * 1e3, 2))
 
+    def warm_up(self, **kw) -> Dict[str, Dict[str, float]]:
+        """First-use costs of every member engine (kernel code objects, launch attributes, the
+        decode graphs of every batch bucket and context class) are paid now instead of by the
+        first questions. The reference's first question costs what every question costs
+        (/root/reference/src/main.rs:428-445); so should ours."""
+        t0 = time.perf_counter()
+        out = {name: b.warm_up(**kw) for name, b in sorted(self.backends.items())}
+        log.info("warm-up: %d decode graph(s) recorded in %.1f s",
+                 sum(int(v.get("graphs", 0)) for v in out.values()), time.perf_counter() - t0)
+        return out
+
     def stats(self) -> Dict[str, Dict[str, float]]:
         """Per-model engine statistics plus a ``consensus`` section (answers/s, latency
         percentiles, rounds, agreement) and a ``device`` section (HBM use)."""

@@ -93,6 +93,9 @@ def main(argv: Optional[list] = None) -> int:
     ap.add_argument("--json", action="store_true", help="print one JSON record per answer")
     ap.add_argument("--strategy", help="override the configured strategy")
     ap.add_argument("--device", help="cuda[:N] or cpu (default: GPU when present)")
+    ap.add_argument("--no-warm-up", action="store_true",
+                    help="skip the start-up warm-up (kernel loading, decode graph recording); the first "
+                         "questions then pay for it")
     ap.add_argument("--distributed", action="store_true",
                     help="one process per GPU under torch.distributed.run: members are placed over the "
                          "node's GPUs by the planner; rank 0 owns the terminal")
@@ -127,6 +130,8 @@ def main(argv: Optional[list] = None) -> int:
         ensemble = leader = LeaderEnsemble(dist_ens)
     else:
         ensemble = build_ensemble(cfg, device)
+    if not args.no_warm_up:
+        ensemble.warm_up()
     if args.questions:
         with open(args.questions) as f:
             answer_file(ensemble, f, as_json=args.json)

@@ -212,9 +212,12 @@ def load_config(path: Optional[str] = None) -> ConsensusConfig:
     text = p.read_text()
     suffix = p.suffix.lower()
     if suffix == ".toml":
-        import tomli
+        try:
+            import tomllib as toml_reader          # standard library from Python 3.11 on
+        except ModuleNotFoundError:
+            import tomli as toml_reader            # the same parser as a package (pyproject installs it below 3.11)
 
-        data = tomli.loads(text)
+        data = toml_reader.loads(text)
     elif suffix in (".yaml", ".yml"):
         import yaml
 

@@ -134,6 +134,11 @@ class Backend:
         scripted backends); lets a driver overlap the steps of several engines."""
         return []
 
+    def warm_up(self, **kw) -> Dict[str, float]:
+        """Pays first-use costs (kernel loading, graph recording) before the first request, where
+        a backend has any; returns what it did. The default has none."""
+        return {}
+
     def token_ids_of(self, text: str) -> Optional[List[int]]:
         """Token ids of ``text`` in this backend's vocabulary (no BOS), or None when the backend
         has no tokenizer of its own (remote, scripted). Strategies that classify answers at the

@@ -124,13 +124,13 @@ def _classify_tokens(backend, results: Sequence[Optional["GenResult"]], choices:
     for i, r in enumerate(rows):
         ids[i, :len(r)] = r
         lens[i] = len(r)
-    out = np.full(len(rows), -1, dtype=np.int32)
-    # one pass per tokenisation form; the first form that finds a class for a row keeps it
-    for k in range(max(len(f) for f in forms)):
-        choice_ids = [f[min(k, len(f) - 1)] if f else -1 for f in forms]
-        got = reducers.answer_extract(ids, lens, marker, choice_ids, window, device=device)
-        out = np.where(out < 0, got, out)
-    return out
+    # Every tokenisation form of every choice goes into ONE extraction call: entry k * C + c is
+    # form k of choice c (-1 where a choice has fewer forms), so the first choice token after
+    # the cue wins whichever form it has, and the entry's index modulo C is its class.
+    C, F = len(forms), max(len(f) for f in forms)
+    choice_ids = [(forms[c][k] if k < len(forms[c]) else -1) for k in range(F) for c in range(C)]
+    got = np.asarray(reducers.answer_extract(ids, lens, marker, choice_ids, window, device=device))
+    return np.where(got >= 0, got % C, -1).astype(np.int32)
 
 
 class MajorityVote:
@@ -184,8 +184,13 @@ class MajorityVote:
                 col = [results[r][i] for r in range(R)]
                 got = _classify_tokens(m.backend, col, self.choices, self.answer_cue, self.cue_window, self.device)
                 if got is not None:
-                    rows = [r for r in range(R) if col[r] is not None]
-                    votes[rows, i] = got[:len(rows)]
+                    # one row per CHAIN of every result; a member's vote is its first chain's
+                    at = 0
+                    for r in range(R):
+                        if col[r] is not None:
+                            if col[r].token_ids:
+                                votes[r, i] = got[at]
+                            at += len(col[r].token_ids)
         for r in range(R):
             for i in range(N):
                 res = results[r][i]

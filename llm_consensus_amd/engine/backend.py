@@ -81,6 +81,7 @@ class EngineBackend(Backend):
         return h
 
     incremental = True
+    RESTART_MARKER = "\n[stream restarted]\n"
 
     def _group_failure(self, e: BaseException) -> None:
         """A failed step of a tensor / expert parallel member cannot be absorbed locally: the
@@ -157,6 +158,14 @@ class EngineBackend(Backend):
             if len(text) > len(sent[i]) and text.startswith(sent[i]):
                 cb(i, text[len(sent[i]):])
                 sent[i] = text
+            elif sent[i] and not sent[i].startswith(text):
+                # The chain no longer extends what the client has seen: the request was preempted
+                # and its recomputation took another numerical path (other batch, other kernel
+                # split) and parted ways on a near-tie. Say so instead of going silent: the
+                # client gets a restart marker followed by the text as it now stands, so what it
+                # has shown and the final result agree again.
+                cb(i, self.RESTART_MARKER + text)
+                sent[i] = text
 
     def _harvest(self, final: bool) -> None:
         for rid in list(self._streams):
@@ -193,6 +202,10 @@ class EngineBackend(Backend):
 
     def engines(self) -> list:
         return [self.engine] if self._pending else []
+
+    def warm_up(self, **kw) -> Dict[str, float]:
+        """See Engine.warm_up (first-use costs paid before the first request)."""
+        return self.engine.warm_up(**kw)
 
     def stats(self) -> Dict[str, float]:
         return self.engine.stats()

@@ -624,6 +624,69 @@ class Engine:
         self.metrics.inc("requests.aborted", len(rids))
         return len(rids)
 
+    def warm_up(self, buckets: Optional[Sequence[int]] = None, ctx_classes: Optional[Sequence[int]] = None,
+                with_prefix: Sequence[bool] = (False,), prompt_tokens: int = 320) -> Dict[str, float]:
+        """Pays the first-use costs before the first real request does: one short request through
+        the whole path (kernel code objects, launch attributes, allocator pools, the group's
+        collectives), then every configured decode step recorded into its hipGraph, in both
+        forms, for ``buckets`` x ``ctx_classes`` x ``with_prefix`` (defaults: every batch bucket,
+        the context classes up to the engine's longest sequence, no shared-prefix pass). The
+        recording runs over rows that are all padding (no KV slot, context length 0), so it
+        touches no request state. A later request whose shape was warmed up finds its graph
+        recorded (``decode.graph_captures`` does not move). In a tensor / expert parallel group
+        every rank must call this with the same arguments. The reference answers its first
+        question as fast as any other (/root/reference/src/main.rs:428-445)."""
+        t0 = time.perf_counter()
+        if self.rt is None:
+            return {"graphs": 0, "seconds": 0.0}      # the CPU plumbing backend has no first-use costs worth paying early
+        if self.has_work():
+            raise RuntimeError("warm_up() runs on an idle engine")
+        n_prompt = max(1, min(prompt_tokens, self.max_model_len - 4))
+        p = core.SamplingParams()
+        p.temperature, p.top_p, p.max_new_tokens, p.ignore_eos = 0.8, 0.95, 3, True
+        vocab = self.model.cfg.vocab_size
+        rid = self.submit([(7 + 13 * i) % vocab for i in range(n_prompt)], params=p, decision_ids=[0, 1])
+        was, self.pipeline_decode = self.pipeline_decode, False
+        try:
+            self.run_until_done()
+        finally:
+            self.pipeline_decode = was
+        self.pop_result(rid)
+        self.kvm.drop_cache()            # the warm-up prompt must not answer prefix look-ups
+        captured = 0
+        if self.use_graphs or self.piecewise:
+            with self._on_stream():
+                for bucket in (buckets if buckets is not None else self.graph_buckets):
+                    if bucket > self.max_batch_seqs or not self.model.decode_capturable(bucket):
+                        continue
+                    for ctx in (ctx_classes if ctx_classes is not None else self.ctx_classes):
+                        if ctx not in self.ctx_classes:
+                            continue
+                        for wp in with_prefix:
+                            key = (bucket, bool(wp), ctx)
+                            g = self._graphs.get(key)
+                            if g is None:
+                                g = self._graphs[key] = _DecodeGraph(self, bucket, bool(wp), ctx)
+                            for with_dec in (False, True):
+                                if g.ready(self, with_dec):
+                                    continue
+                                g.begin_fill()
+                                g.upload()          # the all-padding mirror of a fresh graph
+                                if self.use_graphs:
+                                    g.capture(self, with_dec)
+                                elif self.piecewise == "graphs":
+                                    g.capture_piecewise(self, with_dec)
+                                else:
+                                    g.capture_launch_lists(self, with_dec)
+                                captured += 1
+                                g.rows_key = None
+            if self.rt is not None:
+                torch.cuda.synchronize(self.device)
+        took = time.perf_counter() - t0
+        self.metrics.inc("warmup.graphs", captured)
+        self.metrics.inc("warmup.seconds", took)
+        return {"graphs": captured, "seconds": took}
+
     def pop_result(self, rid: int) -> Optional[RequestOutput]:
         return self._done.pop(rid, None)
 

@@ -127,6 +127,11 @@ class ShardedBackend(Backend):
     def engines(self) -> list:
         return self.local.engines() if self.local is not None else []
 
+    def warm_up(self, **kw) -> Dict[str, float]:
+        """Ranks that host the model warm their engine up (together: a sharded model's warm-up
+        steps contain the group's collectives); the others have nothing to do."""
+        return self.local.warm_up(**kw) if self.local is not None else {}
+
     def stats(self) -> Dict[str, float]:
         return self.local.stats() if self.local is not None else {}
 
@@ -224,6 +229,11 @@ class DistributedEnsemble:
     def stats(self) -> Dict[str, Dict[str, float]]:
         return {n: b.stats() for n, b in self.backends.items()}
 
+    def warm_up(self, **kw) -> Dict[str, Dict[str, float]]:
+        """Every rank warms up the engines it hosts, model by model in name order (the ranks of a
+        sharded model's group meet in its collectives)."""
+        return {n: self.backends[n].warm_up(**kw) for n in sorted(self.backends)}
+
     def collectives(self) -> Dict[str, str]:
         """Which transport every sharded model's group ended up on (peer-to-peer kernels, or the
         bootstrap communicator after a failed first-contact check, with the reason). Collective."""
@@ -264,6 +274,10 @@ class LeaderEnsemble:
     def stats(self) -> Dict[str, Dict[str, float]]:
         return self.inner.stats()
 
+    def warm_up(self, **kw):
+        self.inner.comm.broadcast_object(("warm_up", kw), 0)
+        return self.inner.warm_up(**kw)
+
     def close(self) -> None:
         self.inner.comm.broadcast_object(("stop", None), 0)
 
@@ -276,6 +290,9 @@ def follow(dist_ensemble: DistributedEnsemble) -> int:
         op, qs = dist_ensemble.comm.broadcast_object(None, 0)
         if op == "stop":
             return n
+        if op == "warm_up":
+            dist_ensemble.warm_up(**qs)
+            continue
         dist_ensemble.ask_many(qs)
         n += 1
 

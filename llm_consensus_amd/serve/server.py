@@ -557,6 +557,9 @@ def main(argv: Optional[list] = None) -> int:
     ap.add_argument("--batch-window-ms", type=float, default=5.0)
     ap.add_argument("--distributed", action="store_true",
                     help="one process per GPU under torch.distributed.run; rank 0 serves HTTP")
+    ap.add_argument("--no-warm-up", action="store_true",
+                    help="do not record the decode graphs before the socket opens (the first requests of every "
+                         "batch shape then pay for it)")
     ap.add_argument("--batched", action="store_true",
                     help="answer in closed batches even where the continuous driver applies")
     args = ap.parse_args(argv)
@@ -572,6 +575,8 @@ def main(argv: Optional[list] = None) -> int:
         ens = LeaderEnsemble(dist_ens)
     else:
         ens = build_ensemble(cfg)
+    if not args.no_warm_up:
+        ens.warm_up()
     try:
         ConsensusServer(ens, args.host, args.port, args.max_batch, args.batch_window_ms,
                         continuous=not args.batched).serve_forever()

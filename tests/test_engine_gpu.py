@@ -290,3 +290,40 @@ def test_back_to_back_steps_that_sample_nothing_do_not_mix_their_inputs():
         torch.cuda.synchronize()
         want = one.pop_result(r).embedding
         assert np.allclose(g, want, atol=2e-2), float(np.abs(g - want).max())
+
+
+def test_warm_up_records_every_configured_decode_graph_before_the_first_request():
+    """After Engine.warm_up() no request of a warmed-up shape records anything: the first request
+    costs what a later one costs (/root/reference/src/main.rs:428-445 answers its first question
+    like any other)."""
+    import time
+
+    m = TransformerModel.random_init(get_preset("small-llama"), "cuda", seed=2, std=0.05)
+    eng = Engine(m, num_kv_blocks=256, block_size=16, max_model_len=512, graph_buckets=(1, 2, 4, 8))
+    rep = eng.warm_up()
+    n_classes = len(eng.ctx_classes)
+    assert rep["graphs"] >= 1 and eng.stats()["rt.graphs"] == 4 * n_classes * 2      # buckets x classes x forms
+    before = eng.stats().get("decode.graph_captures", 0)
+
+    def ask(n_req, new):
+        t0 = time.perf_counter()
+        rids = [eng.submit(list(range(5 + i, 90 + i)), params=params(new, seed=i, temperature=0.8, top_p=0.9),
+                           decision_ids=[3, 4] if i % 2 else None) for i in range(n_req)]
+        eng.run_until_done()
+        torch.cuda.synchronize()
+        outs = [eng.pop_result(r) for r in rids]
+        assert all(len(o.token_ids[0]) == new for o in outs)
+        return time.perf_counter() - t0
+
+    first = ask(3, 12)
+    assert eng.stats().get("decode.graph_captures", 0) == before       # nothing was recorded while serving
+    steady = min(ask(3, 12) for _ in range(3))
+    assert first < 1.5 * steady + 0.02, (first, steady)
+    ask(7, 5)
+    ask(1, 20)
+    assert eng.stats().get("decode.graph_captures", 0) == before
+    # a cold engine of the same shape does record while serving
+    cold = Engine(m, num_kv_blocks=256, block_size=16, max_model_len=512, graph_buckets=(1, 2, 4, 8))
+    r = cold.submit(list(range(5, 90)), params=params(4))
+    cold.run_until_done()
+    assert cold.stats()["decode.graph_captures"] >= 1 and cold.pop_result(r) is not None

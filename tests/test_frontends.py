@@ -287,3 +287,27 @@ def test_packaging_manifest_names_real_entry_points():
     assert "build_core" in setup_src and "build_kernels" in setup_src
     # the package itself must be importable without the hyphenated compatibility link
     assert importlib.import_module("llm_consensus_amd.workloads").make_questions
+
+
+def test_toml_configs_load_with_the_standard_library_parser(monkeypatch):
+    """Python 3.11+ has no ``tomli`` unless it is installed separately; the loader must use
+    ``tomllib`` there. Simulated by offering ``tomllib`` and hiding ``tomli``."""
+    import builtins
+    import sys
+    import types
+
+    import tomli
+
+    fake = types.ModuleType("tomllib")
+    fake.loads = tomli.loads
+    monkeypatch.setitem(sys.modules, "tomllib", fake)
+    real_import = builtins.__import__
+
+    def no_tomli(name, *a, **k):
+        if name == "tomli":
+            raise ModuleNotFoundError("No module named 'tomli'")
+        return real_import(name, *a, **k)
+
+    monkeypatch.setattr(builtins, "__import__", no_tomli)
+    for f in sorted(CONFIGS.glob("*.toml")):
+        assert load_config(str(f)).members, f.name

@@ -437,6 +437,38 @@ def test_sampler_matches_reference_definition(V):
     assert torch.allclose(lp.cpu()[m], wl[m], atol=2e-3)
 
 
+@pytest.mark.parametrize("top_p", [0.5, 0.9, 0.95, 0.99])
+def test_top_p_threshold_resolution_on_flat_distributions(top_p):
+    """The nucleus cut is found by a threshold search with a resolution of about 1.4e-3 in units
+    of logit / temperature (four 12-way sweeps over a range of 30). On flat distributions (what
+    random-init models produce: tens of thousands of near-tied entries) entries that close to
+    the exact cut may be kept or dropped differently from the exact top-p of the host oracle.
+    Pinned here: over many seeds the kernel's token equals the oracle's for almost every row, and
+    where it differs BOTH tokens lie within that resolution of the exact cut (each such entry
+    carries ~1e-5 of the mass). No reference fixture covers this: parity is otherwise unpinned."""
+    V, R, T = 32000, 192, 0.8
+    logits = rand(R, V, scale=0.35, seed=int(top_p * 100))       # flat: the nucleus holds most of the vocabulary
+    temp = torch.full((R,), T)
+    tp = torch.full((R,), top_p)
+    seeds = torch.arange(R, dtype=torch.int64) * 104729 + 11
+    steps = torch.arange(R, dtype=torch.int32) % 7
+    tok, _ = ops.sample(logits.to(DEV), temp.to(DEV), tp.to(DEV), None, seeds.to(DEV), steps.to(DEV))
+    want, _ = ref.sample(logits, temp, tp, torch.zeros(R, dtype=torch.int32), seeds, steps)
+    tok = tok.cpu()
+    diff = torch.nonzero(tok != want).flatten().tolist()
+    # an entry kept or dropped at the cut moves the kept mass by ~1e-5, which can carry the draw
+    # over the boundary to the neighbouring kept entry: still a draw from (almost) the same nucleus
+    print(f"top_p={top_p}: {len(diff)} of {R} rows differ from the exact-threshold oracle")
+    assert len(diff) <= R // 4, (len(diff), diff[:8])
+    scaled = logits / T
+    for r in diff:
+        srt, _ = torch.sort(scaled[r], descending=True)
+        cdf = torch.cumsum(torch.softmax(srt, -1), -1)
+        cut = float(srt[int(torch.searchsorted(cdf, torch.tensor(top_p)))])
+        for t in (int(tok[r]), int(want[r])):
+            assert float(scaled[r, t]) >= cut - 5e-3, (r, t, float(scaled[r, t]), cut)
+
+
 def test_sampler_never_returns_an_out_of_range_token_for_poisoned_rows():
     """All-NaN and all -inf rows (what a failed forward pass leaves behind) have no arg-max; the
     kernel must still hand back a token inside the vocabulary and must not index with a sentinel."""

@@ -142,3 +142,15 @@ def test_token_level_decisions_in_the_vote_strategies():
     assert [v["class"] for v in out[1].votes] == [3, 0, -1, 2]
     with pytest.raises(ValueError):
         MajorityVote(members, decision_mode="nope")
+    # members whose calls return several chains (GenParams.n > 1): a member's vote is chain 0 of
+    # ITS result for THAT question; the rows of the other chains must not shift later questions
+    gp3 = GenParams(max_new_tokens=8, n=3)
+    members = [Member(personas[i], Canned(["Answer: A", "Answer: B", "Answer: C", "Answer: D"]), params=gp3)
+               for i in range(2)]
+    res = MajorityVote(members, decision_mode="tokens").ask_many(["q0", "q1", "q2"])
+    assert [[v["class"] for v in r.votes] for r in res] == [[0, 0], [1, 1], [2, 2]]
+    # the two tokenisation forms of the choices interleave after the cue ("Answer: C" is form
+    # " C", "Answer:D" is form "D"): the FIRST choice token wins, whichever form it has
+    one = [Member(personas[0], Canned(["Answer:D then C", "Answer: C then:D"]), params=gp)]
+    res = MajorityVote(one, decision_mode="tokens", cue_window=12).ask_many(["q0", "q1"])
+    assert [r.votes[0]["class"] for r in res] == [3, 2]

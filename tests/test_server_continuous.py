@@ -91,3 +91,25 @@ def test_direct_completion_outliving_the_vote_questions_is_stepped_by_one_driver
                 assert st == 200 and body["usage"]["total_tokens"] > 0, body
     finally:
         srv.shutdown()
+
+
+def test_streamed_text_that_diverges_after_a_preemption_is_restarted_not_silenced():
+    """Token streaming decodes the whole chain every step and sends what is new. A preempted
+    request is recomputed; should the regenerated chain differ from what was already sent, the
+    client is told (restart marker + the text as it now stands) instead of getting nothing more."""
+    from llm_consensus_amd.engine.backend import EngineBackend
+    from llm_consensus_amd.utils.tokenizer import ByteLevelTokenizer
+
+    be = EngineBackend.__new__(EngineBackend)
+    be.tok = ByteLevelTokenizer()
+    got = []
+    be._streams = {7: [lambda chain, text: got.append((chain, text)), [""]]}
+    enc = lambda s: list(be.tok.encode(s, add_bos=False))  # noqa: E731
+    be._emit(7, [enc("The answer")], final=False)
+    be._emit(7, [enc("The answer is")], final=False)
+    be._emit(7, [enc("The")], final=False)                    # preempted: the chain restarts, a prefix so far
+    be._emit(7, [enc("The reply is B")], final=False)         # and then leaves what was sent
+    be._emit(7, [enc("The reply is B.")], final=True)
+    assert got[0] == (0, "The answer") and got[1] == (0, " is")
+    assert got[2] == (0, EngineBackend.RESTART_MARKER + "The reply is B")
+    assert got[3] == (0, ".") and len(got) == 4
