@@ -222,7 +222,66 @@ __global__ __launch_bounds__(256) void l2_normalize_kernel(const float* __restri
   for (int c = threadIdx.x; c < d; c += blockDim.x) y[static_cast<size_t>(blockIdx.x) * d + c] = xr[c] * inv;
 }
 
+// y[i] += x[i] (fp32): chunk sums of a pooled embedding that spans several prefill steps.
+__global__ void accumulate_f32_kernel(float* __restrict__ y, const float* __restrict__ x, long long n) {
+  for (long long i = blockIdx.x * static_cast<long long>(blockDim.x) + threadIdx.x; i < n;
+       i += static_cast<long long>(gridDim.x) * blockDim.x)
+    y[i] += x[i];
+}
+
+// out[r, c] = x[r, c] for c < n, `fill` for n <= c < n_pad (fp32 rows widened to a common width).
+__global__ void pad_cols_f32_kernel(const float* __restrict__ x, float* __restrict__ out, int R, int n, int n_pad,
+                                    float fill) {
+  const long long total = static_cast<long long>(R) * n_pad;
+  for (long long i = blockIdx.x * static_cast<long long>(blockDim.x) + threadIdx.x; i < total;
+       i += static_cast<long long>(gridDim.x) * blockDim.x) {
+    const int r = static_cast<int>(i / n_pad), c = static_cast<int>(i % n_pad);
+    out[i] = c < n ? x[static_cast<size_t>(r) * n + c] : fill;
+  }
+}
+
+// out[r, w * c + j] = parts[w, r, j] for w * c + j < total (units of 2 bytes): the column
+// all-gather's [W, R, c] blocks laid side by side, ragged last shard cut off.
+__global__ void concat_cols_kernel(const uint16_t* __restrict__ parts, int W, int R, int c, int total,
+                                   uint16_t* __restrict__ out) {
+  const long long n = static_cast<long long>(R) * total;
+  for (long long i = blockIdx.x * static_cast<long long>(blockDim.x) + threadIdx.x; i < n;
+       i += static_cast<long long>(gridDim.x) * blockDim.x) {
+    const int r = static_cast<int>(i / total), col = static_cast<int>(i % total);
+    const int w = col / c, j = col % c;
+    out[i] = parts[(static_cast<size_t>(w) * R + r) * c + j];
+  }
+}
+
 }  // namespace
+
+LC_EXPORT int lc_concat_cols(const void* parts, int W, int R, int c_units, int total_units, void* out,
+                             hipStream_t stream) {
+  if (R <= 0 || total_units <= 0) return 0;
+  if (W < 1 || c_units < 1 || total_units > W * c_units) return -1;
+  const long long n = static_cast<long long>(R) * total_units;
+  const int grid = static_cast<int>(std::min<long long>((n + 255) / 256, 8192));
+  concat_cols_kernel<<<dim3(grid), dim3(256), 0, stream>>>(static_cast<const uint16_t*>(parts), W, R, c_units,
+                                                          total_units, static_cast<uint16_t*>(out));
+  LC_RETURN_LAST_ERROR();
+}
+
+LC_EXPORT int lc_accumulate_f32(void* y, const void* x, long long n, hipStream_t stream) {
+  if (n <= 0) return 0;
+  const int grid = static_cast<int>(std::min<long long>((n + 255) / 256, 1024));
+  accumulate_f32_kernel<<<dim3(grid), dim3(256), 0, stream>>>(static_cast<float*>(y), static_cast<const float*>(x), n);
+  LC_RETURN_LAST_ERROR();
+}
+
+LC_EXPORT int lc_pad_cols_f32(const void* x, void* out, int R, int n, int n_pad, float fill, hipStream_t stream) {
+  if (R <= 0 || n_pad <= 0) return 0;
+  if (n > n_pad) return -1;
+  const long long total = static_cast<long long>(R) * n_pad;
+  const int grid = static_cast<int>(std::min<long long>((total + 255) / 256, 4096));
+  pad_cols_f32_kernel<<<dim3(grid), dim3(256), 0, stream>>>(static_cast<const float*>(x), static_cast<float*>(out), R,
+                                                           n, n_pad, fill);
+  LC_RETURN_LAST_ERROR();
+}
 
 LC_EXPORT int lc_embed_gather(const void* ids, const void* E, void* x, int T, int d, int vocab,
                               const void* feed_tok, const void* feed_rows, hipStream_t stream) {

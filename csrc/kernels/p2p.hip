@@ -163,6 +163,8 @@ struct ReduceArgs {
   float eps;
   unsigned long long timeout;
   int publish_only;       // stage + flag the local rows, skip the wait and the reduction (y, h untouched)
+  size_t slab_stride;     // elements between two slabs of `part` (T * d, or more when the T rows are a
+                          // range of a taller slab stack)
 };
 
 // The local partial row chunk (8 elements) as fp32.
@@ -172,7 +174,7 @@ LC_DEVICE void local_chunk(const ReduceArgs& a, int r, int c, float* f) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) f[j] = 0.f;
     for (int s = 0; s < a.S; ++s) {
-      const float4* p = reinterpret_cast<const float4*>(a.part + static_cast<size_t>(s) * a.T * a.d + off);
+      const float4* p = reinterpret_cast<const float4*>(a.part + static_cast<size_t>(s) * a.slab_stride + off);
       const float4 lo = p[0], hi = p[1];
       f[0] += lo.x; f[1] += lo.y; f[2] += lo.z; f[3] += lo.w;
       f[4] += hi.x; f[5] += hi.y; f[6] += hi.z; f[7] += hi.w;
@@ -387,40 +389,150 @@ __global__ __launch_bounds__(kThreads, 2) void p2p_allreduce2_kernel(P2PPeers pe
 struct ExchangeArgs {
   const char* src;   // local input: nblk blocks of m bytes
   char* out;         // W blocks of m bytes: block s = what rank s contributed
-  uint32_t m;        // bytes per block (multiple of 16)
+  uint32_t m;        // bytes per block
+  uint32_t m_pad;    // bytes per block inside the staging slot (m rounded up to 16)
   int nblk;          // 1: all-gather (everyone reads block 0 of every peer); W: all-to-all (rank q reads block q)
   int rank;
   unsigned long long timeout;
   int publish_only;  // stage + flag only (see lc_p2p_allreduce)
 };
 
+LC_DEVICE uint32_t load4_sys(__amdgpu_buffer_rsrc_t r, uint32_t off) {
+  return __builtin_amdgcn_raw_buffer_load_b32(r, off, 0, 17);
+}
+LC_DEVICE void store4_sys(__amdgpu_buffer_rsrc_t r, uint32_t off, uint32_t v) {
+  __builtin_amdgcn_raw_buffer_store_b32(v, r, off, 0, 17);
+}
+
 // All-gather / equal-split all-to-all of raw bytes. Block b owns the 16-byte chunks j with
-// (j / chunks_per_block) == b of EVERY m-byte block, on the publishing and the reading side.
+// (j / chunks_per_block) == b of EVERY block, on the publishing and the reading side. Blocks of
+// m bytes that are not a multiple of 16 (a handful of counters, odd row widths) take the
+// narrow form: 4-byte units through the staging slot, whose blocks are m_pad apart; the last
+// unit of a block whose length is not a multiple of 4 is assembled bytewise, so neither the
+// input nor the output is touched beyond m bytes per block.
 template <int W>
 __global__ __launch_bounds__(kThreads) void p2p_exchange_kernel(P2PPeers peers, P2PRegion reg, ExchangeArgs a) {
   __shared__ int ok;
   char* self = peers.base[a.rank];
   const uint32_t epoch = reinterpret_cast<const Header*>(self)->epoch + 1;
   const uint32_t slot_off = reg.stage + (epoch & 1u) * reg.stage_bytes;
-  const uint32_t chunks = a.m >> 4;
+  const bool wide = (a.m & 15u) == 0;
+  const uint32_t unit = wide ? 16u : 4u;
+  const uint32_t chunks = (a.m + unit - 1) / unit;
   const uint32_t cpb = (chunks + gridDim.x - 1) / gridDim.x;
   const uint32_t j0 = blockIdx.x * cpb, j1 = min(chunks, j0 + cpb);
   {
     const __amdgpu_buffer_rsrc_t mine = rsrc_of(self + slot_off, reg.stage_bytes);
     for (int t = 0; t < a.nblk; ++t)
       for (uint32_t j = j0 + threadIdx.x; j < j1; j += kThreads) {
-        const uint32_t off = t * a.m + j * 16;
-        store16_sys(mine, off, *reinterpret_cast<const u32x4*>(a.src + off));
+        if (wide) {
+          store16_sys(mine, t * a.m_pad + j * 16, *reinterpret_cast<const u32x4*>(a.src + static_cast<size_t>(t) * a.m + j * 16));
+        } else {
+          const char* p = a.src + static_cast<size_t>(t) * a.m + j * 4;
+          uint32_t v = 0;
+          const uint32_t nb = min(4u, a.m - j * 4);
+          if (nb == 4 && (reinterpret_cast<uintptr_t>(p) & 3) == 0) {
+            v = *reinterpret_cast<const uint32_t*>(p);
+          } else {
+            for (uint32_t k = 0; k < nb; ++k) v |= static_cast<uint32_t>(static_cast<uint8_t>(p[k])) << (8 * k);
+          }
+          store4_sys(mine, t * a.m_pad + j * 4, v);
+        }
       }
   }
   publish<W>(peers, reg.flags1, a.rank, epoch);
   if (!a.publish_only && wait_peers<W>(self, reg.flags1, a.rank, epoch, a.timeout, &ok)) {
-    const uint32_t sel = a.nblk == 1 ? 0u : static_cast<uint32_t>(a.rank) * a.m;
+    const uint32_t sel = a.nblk == 1 ? 0u : static_cast<uint32_t>(a.rank) * a.m_pad;
 #pragma unroll
     for (int s = 0; s < W; ++s) {
       const __amdgpu_buffer_rsrc_t src = rsrc_of(peers.base[s] + slot_off, reg.stage_bytes);
-      for (uint32_t j = j0 + threadIdx.x; j < j1; j += kThreads)
-        *reinterpret_cast<u32x4*>(a.out + static_cast<size_t>(s) * a.m + j * 16) = load16_sys(src, sel + j * 16);
+      for (uint32_t j = j0 + threadIdx.x; j < j1; j += kThreads) {
+        if (wide) {
+          *reinterpret_cast<u32x4*>(a.out + static_cast<size_t>(s) * a.m + j * 16) = load16_sys(src, sel + j * 16);
+        } else {
+          const uint32_t v = load4_sys(src, sel + j * 4);
+          char* q = a.out + static_cast<size_t>(s) * a.m + j * 4;
+          const uint32_t nb = min(4u, a.m - j * 4);
+          if (nb == 4 && (reinterpret_cast<uintptr_t>(q) & 3) == 0) {
+            *reinterpret_cast<uint32_t*>(q) = v;
+          } else {
+            for (uint32_t k = 0; k < nb; ++k) q[k] = static_cast<char>((v >> (8 * k)) & 0xffu);
+          }
+        }
+      }
+    }
+  }
+  finish_call(self, epoch);
+}
+
+struct CountedArgs {
+  const char* src;        // W blocks of cap rows: block t holds the rows bound for rank t
+  char* out;              // W blocks of cap rows: block s receives the rows rank s sent here
+  const int32_t* counts;  // [W * per] rows per (destination rank, slot); a destination's rows = sum of its `per` slots
+  int32_t* recv_counts;   // [W * per] out: entry s * per + e = what rank s reports for (this rank, slot e); may be null
+  uint32_t row_bytes;     // multiple of 16
+  uint32_t cap;           // rows per block
+  int per, rank;
+  unsigned long long timeout;
+};
+
+constexpr uint32_t kCountHeader = 4096;   // bytes at the head of the staging slot that carry the counts
+
+// All-to-all of row blocks with device-side row counts: only the rows that exist cross the
+// fabric, although every (source, destination) pair owns `cap` rows of both buffers. The
+// publisher puts its whole count table at the head of its staging slot; a reader sums the `per`
+// entries addressed to it to learn how many rows to fetch from that peer, and hands the entries
+// on as recv_counts. Nothing about the counts is known to the host: an expert-parallel MoE layer
+// of any size is plain kernel launches (capturable, no read-back). Rows of `out` beyond the
+// counts are left untouched.
+template <int W>
+__global__ __launch_bounds__(kThreads) void p2p_exchange_counted_kernel(P2PPeers peers, P2PRegion reg, CountedArgs a) {
+  __shared__ int ok;
+  __shared__ uint32_t rows_to[W], rows_from[W];
+  char* self = peers.base[a.rank];
+  const uint32_t epoch = reinterpret_cast<const Header*>(self)->epoch + 1;
+  const uint32_t slot_off = reg.stage + (epoch & 1u) * reg.stage_bytes;
+  const uint32_t block_bytes = a.cap * a.row_bytes;
+  const uint32_t cpr = a.row_bytes >> 4;                               // 16-byte chunks per row
+  const uint32_t chunks = a.cap * cpr;                                 // per block, at most
+  const uint32_t cpb = (chunks + gridDim.x - 1) / gridDim.x;
+  const uint32_t j0 = blockIdx.x * cpb, j1 = min(chunks, j0 + cpb);
+  const __amdgpu_buffer_rsrc_t mine = rsrc_of(self + slot_off, reg.stage_bytes);
+  if (threadIdx.x < W) {
+    uint32_t n = 0;
+    for (int e = 0; e < a.per; ++e) n += static_cast<uint32_t>(max(0, a.counts[threadIdx.x * a.per + e]));
+    rows_to[threadIdx.x] = min(n, a.cap);
+  }
+  // every block publishes the count table (same values; a reader may be served by any of them)
+  for (uint32_t i = threadIdx.x; i < static_cast<uint32_t>(W * a.per); i += kThreads)
+    store4_sys(mine, i * 4, static_cast<uint32_t>(a.counts[i]));
+  __syncthreads();
+  for (int t = 0; t < W; ++t) {
+    const uint32_t lim = min(j1, rows_to[t] * cpr);
+    for (uint32_t j = j0 + threadIdx.x; j < lim; j += kThreads)
+      store16_sys(mine, kCountHeader + t * block_bytes + j * 16,
+                  *reinterpret_cast<const u32x4*>(a.src + static_cast<size_t>(t) * block_bytes + j * 16));
+  }
+  publish<W>(peers, reg.flags1, a.rank, epoch);
+  if (wait_peers<W>(self, reg.flags1, a.rank, epoch, a.timeout, &ok)) {
+    if (threadIdx.x < W) {
+      const __amdgpu_buffer_rsrc_t src = rsrc_of(peers.base[threadIdx.x] + slot_off, reg.stage_bytes);
+      uint32_t n = 0;
+      for (int e = 0; e < a.per; ++e) {
+        const int32_t c = static_cast<int32_t>(load4_sys(src, (a.rank * a.per + e) * 4));
+        n += static_cast<uint32_t>(max(0, c));
+        if (blockIdx.x == 0 && a.recv_counts != nullptr) a.recv_counts[threadIdx.x * a.per + e] = c;
+      }
+      rows_from[threadIdx.x] = min(n, a.cap);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < W; ++s) {
+      const __amdgpu_buffer_rsrc_t src = rsrc_of(peers.base[s] + slot_off, reg.stage_bytes);
+      const uint32_t lim = min(j1, rows_from[s] * cpr);
+      for (uint32_t j = j0 + threadIdx.x; j < lim; j += kThreads)
+        *reinterpret_cast<u32x4*>(a.out + static_cast<size_t>(s) * block_bytes + j * 16) =
+            load16_sys(src, kCountHeader + a.rank * block_bytes + j * 16);
     }
   }
   finish_call(self, epoch);
@@ -543,21 +655,22 @@ LC_EXPORT void lc_p2p_comm_set_timeout(void* comm, double timeout_s) {
   }
 
 // y = RMSNorm(h += sum over ranks of the local partial product) * w   (h, w given), or
-// y = sum over ranks (h null). The local partial is either S fp32 slabs [S, T, d] (`part`) or a
-// bf16 [T, d] tensor (`xin`). two_shot selects the reduce-scatter + all-gather form. Every
+// y = sum over ranks (h null). The local partial is either S fp32 slabs [S, T, d] (`part`;
+// `slab_stride` elements apart, 0 = T * d) or a bf16 [T, d] tensor (`xin`). two_shot selects the reduce-scatter + all-gather form. Every
 // rank must make the same call (same T, d, two_shot).
 // publish_only (one-shot form only) is for measurements where the peers of the rank under
 // test merely have to play their part of the protocol: they stage their rows, raise their
 // flags and leave, without waiting for anybody or holding a CU while they do.
-LC_EXPORT int lc_p2p_allreduce(void* comm, const void* part, int S, const void* xin, void* h, const void* w, void* y,
-                               int T, int d, float eps, int two_shot, int publish_only, hipStream_t stream) {
+LC_EXPORT int lc_p2p_allreduce(void* comm, const void* part, int S, long long slab_stride, const void* xin, void* h,
+                               const void* w, void* y, int T, int d, float eps, int two_shot, int publish_only,
+                               hipStream_t stream) {
   CommState* c = static_cast<CommState*>(comm);
   if (T <= 0) return 0;
   if (d % 8 || d > 8 * kThreads * 8 || (part == nullptr) == (xin == nullptr) || (part && S < 1) || (h && !w)) return -1;
   if (static_cast<size_t>(T) * d * 2 > c->reg.stage_bytes) return -2;
   ReduceArgs a{static_cast<const float*>(part), static_cast<const bf16_t*>(xin), static_cast<bf16_t*>(h),
                static_cast<const bf16_t*>(w), static_cast<bf16_t*>(y), S, T, d, c->rank, eps, c->timeout,
-               publish_only};
+               publish_only, slab_stride > 0 ? static_cast<size_t>(slab_stride) : static_cast<size_t>(T) * d};
   if (publish_only && two_shot) return -1;
   const dim3 grid(grid_for_rows(T, c->grid_cap)), block(kThreads);
   const int maxc = d <= 8 * kThreads ? 1 : (d <= 32 * kThreads ? 4 : 8);
@@ -582,20 +695,49 @@ LC_EXPORT int lc_p2p_allreduce(void* comm, const void* part, int S, const void* 
 }
 
 // All-gather (nblk = 1: src holds m bytes, out world * m) or equal-split all-to-all (nblk =
-// world: src and out hold world blocks of m bytes). m must be a multiple of 16.
+// world: src and out hold world blocks of m bytes). Any m > 0.
 LC_EXPORT int lc_p2p_exchange(void* comm, const void* src, void* out, long long m, int all_to_all,
                               int publish_only, hipStream_t stream) {
   CommState* c = static_cast<CommState*>(comm);
   if (m <= 0) return 0;
   const int nblk = all_to_all ? c->world : 1;
-  if (m % 16 || static_cast<size_t>(m) * nblk > c->reg.stage_bytes) return m % 16 ? -1 : -2;
-  ExchangeArgs a{static_cast<const char*>(src), static_cast<char*>(out), static_cast<uint32_t>(m), nblk, c->rank,
-                 c->timeout, publish_only};
-  const long long chunks = m / 16;
+  const long long m_pad = (m + 15) / 16 * 16;
+  if (static_cast<size_t>(m_pad) * nblk > c->reg.stage_bytes) return -2;
+  ExchangeArgs a{static_cast<const char*>(src), static_cast<char*>(out), static_cast<uint32_t>(m),
+                 static_cast<uint32_t>(m_pad), nblk, c->rank, c->timeout, publish_only};
+  const long long chunks = m_pad / 16;
   const int blocks = static_cast<int>(std::max<long long>(1, std::min<long long>(c->grid_cap, (chunks + 1023) / 1024)));
   const dim3 grid(blocks), block(kThreads);
 #define LC_LAUNCHX(W_, unused) p2p_exchange_kernel<W_><<<grid, block, 0, stream>>>(c->peers, c->reg, a)
   LC_P2P_BY_WORLD(LC_LAUNCHX, 0)
 #undef LC_LAUNCHX
+  LC_RETURN_LAST_ERROR();
+}
+
+// Rows a counted exchange can carry per (source, destination) pair for rows of `row_bytes`.
+LC_EXPORT long long lc_p2p_counted_cap(void* comm, long long row_bytes) {
+  CommState* c = static_cast<CommState*>(comm);
+  if (row_bytes <= 0 || c->reg.stage_bytes <= kCountHeader) return 0;
+  return static_cast<long long>((c->reg.stage_bytes - kCountHeader) / (static_cast<size_t>(c->world) * row_bytes));
+}
+
+// All-to-all of row blocks with device-side counts (see p2p_exchange_counted_kernel). src / out:
+// world blocks of cap rows of row_bytes (a multiple of 16); counts: int32 [world * per] on the
+// device; recv_counts: int32 [world * per] out (or null).
+LC_EXPORT int lc_p2p_exchange_counted(void* comm, const void* src, void* out, long long row_bytes, int cap,
+                                      const void* counts, int per, void* recv_counts, hipStream_t stream) {
+  CommState* c = static_cast<CommState*>(comm);
+  if (cap <= 0) return 0;
+  if (row_bytes <= 0 || row_bytes % 16 || per < 1 || static_cast<size_t>(c->world) * per * 4 > kCountHeader) return -1;
+  if (kCountHeader + static_cast<size_t>(c->world) * cap * row_bytes > c->reg.stage_bytes) return -2;
+  CountedArgs a{static_cast<const char*>(src), static_cast<char*>(out), static_cast<const int32_t*>(counts),
+                static_cast<int32_t*>(recv_counts), static_cast<uint32_t>(row_bytes), static_cast<uint32_t>(cap), per,
+                c->rank, c->timeout};
+  const long long chunks = static_cast<long long>(cap) * (row_bytes / 16);
+  const int blocks = static_cast<int>(std::max<long long>(1, std::min<long long>(c->grid_cap, (chunks + 1023) / 1024)));
+  const dim3 grid(blocks), block(kThreads);
+#define LC_LAUNCHC(W_, unused) p2p_exchange_counted_kernel<W_><<<grid, block, 0, stream>>>(c->peers, c->reg, a)
+  LC_P2P_BY_WORLD(LC_LAUNCHC, 0)
+#undef LC_LAUNCHC
   LC_RETURN_LAST_ERROR();
 }

@@ -351,7 +351,80 @@ __global__ __launch_bounds__(kThreads) void logprob_gather_kernel(
   }
 }
 
+// Vocabulary-parallel form: this rank holds columns [vocab_lo, vocab_lo + V) of the logits.
+// out[r, c] = logits[r][ids[r, c] - vocab_lo] when the id falls into this shard, else 0;
+// out[r, C] = log-sum-exp of the shard's row; columns C + 1 .. Cp - 1 (padding that keeps a row
+// a multiple of 16 bytes for the exchange) are zero. The ranks exchange these Cp numbers per row
+// instead of the logits and logprob_merge_kernel finishes the log-softmax.
+__global__ __launch_bounds__(kThreads) void logit_targets_shard_kernel(
+    const float* __restrict__ logits, int V, int ld, const int32_t* __restrict__ row_index,
+    const int32_t* __restrict__ ids, int id_stride, int C, int Cp, int vocab_lo, float* __restrict__ out) {
+  __shared__ float red[16];
+  const int r = blockIdx.x;
+  const float* row = logits + static_cast<size_t>(row_index ? row_index[r] : r) * ld;
+  const bool vec = (V % 4 == 0) && ((reinterpret_cast<uintptr_t>(row) & 15) == 0);
+  float mx = -INFINITY, s = 0.f;
+  for_each_strided(row, V, vec, [&](float x, int) {
+    if (x > mx) {
+      s = s * __expf(mx - x) + 1.f;
+      mx = x;
+    } else {
+      s += __expf(x - mx);
+    }
+  });
+  const float bmx = block_max(mx, red);
+  s = block_sum(mx == -INFINITY ? 0.f : s * __expf(mx - bmx), red);
+  const float lse = bmx + __logf(s);
+  for (int c = threadIdx.x; c < Cp; c += blockDim.x) {
+    float v = 0.f;
+    if (c < C) {
+      const int id = ids[static_cast<size_t>(r) * id_stride + c] - vocab_lo;
+      if (id >= 0 && id < V) v = row[id];
+    } else if (c == C) {
+      v = lse;
+    }
+    out[static_cast<size_t>(r) * Cp + c] = v;
+  }
+}
+
+// parts [W, R, Cp] from logit_targets_shard_kernel of W ranks -> out[r, c] = sum_w parts[w, r, c]
+// - logsumexp_w parts[w, r, C]. One thread per (row, target).
+__global__ void logprob_merge_kernel(const float* __restrict__ parts, int W, int R, int C, int Cp,
+                                     float* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= R * C) return;
+  const int r = i / C, c = i % C;
+  float mx = -INFINITY;
+  for (int w = 0; w < W; ++w) mx = fmaxf(mx, parts[(static_cast<size_t>(w) * R + r) * Cp + C]);
+  float z = 0.f, v = 0.f;
+  for (int w = 0; w < W; ++w) {
+    const float* p = parts + (static_cast<size_t>(w) * R + r) * Cp;
+    z += __expf(p[C] - mx);
+    v += p[c];
+  }
+  out[i] = v - (mx + __logf(z));
+}
+
 }  // namespace
+
+LC_EXPORT int lc_logit_targets_shard(const void* logits, int V, int ld, const void* row_index, const void* ids,
+                                     int id_stride, int C, int Cp, int vocab_lo, void* out, int R,
+                                     hipStream_t stream) {
+  if (R <= 0) return 0;
+  if (C <= 0 || Cp <= C) return -1;
+  logit_targets_shard_kernel<<<dim3(R), dim3(kThreads), 0, stream>>>(
+      static_cast<const float*>(logits), V, ld, static_cast<const int32_t*>(row_index),
+      static_cast<const int32_t*>(ids), id_stride, C, Cp, vocab_lo, static_cast<float*>(out));
+  LC_RETURN_LAST_ERROR();
+}
+
+LC_EXPORT int lc_logprob_merge(const void* parts, int W, int R, int C, int Cp, void* out, hipStream_t stream) {
+  if (R <= 0 || C <= 0) return 0;
+  if (W < 1 || Cp <= C) return -1;
+  logprob_merge_kernel<<<dim3((R * C + 255) / 256), dim3(256), 0, stream>>>(static_cast<const float*>(parts), W, R, C,
+                                                                           Cp, static_cast<float*>(out));
+  LC_RETURN_LAST_ERROR();
+}
 
 LC_EXPORT int lc_sample(const void* logits, int V, int ld, const void* row_index, const void* temperature,
                         const void* top_p, const void* top_k, const void* seeds, const void* steps,

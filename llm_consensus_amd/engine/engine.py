@@ -461,6 +461,67 @@ class _StepStaging:
         return self.dev[off:off + a.nbytes].view(self._TORCH[a.dtype]).view(a.shape)
 
 
+class _StepLanding:
+    """Results of one prefill step on their way to the host: every tensor is copied into ONE
+    pinned buffer with an asynchronous copy queued right behind the kernel that produced it, and
+    the host waits once (``wait``) before it reads any of them. Two of these alternate per
+    engine, so the buffer a finished step is still being read from is never the one the next
+    step's copies land in."""
+
+    _NP = {torch.int32: np.int32, torch.float32: np.float32}
+
+    def __init__(self, device: torch.device) -> None:
+        self.device = device
+        self.cap = 0
+        self.host: Optional[np.ndarray] = None
+        self.used = 0
+        self.items: List[tuple] = []
+        self.done: Optional[rt.Event] = None
+
+    def begin(self) -> None:
+        self.used, self.items = 0, []
+
+    def take(self, t: torch.Tensor) -> int:
+        """Queues the copy of ``t`` (int32 / float32, contiguous) to the host; returns a ticket."""
+        t = t.contiguous()
+        nbytes = t.numel() * t.element_size()
+        if self.device.type != "cuda":
+            self.items.append((t.numpy().copy(), None, None))
+            return len(self.items) - 1
+        off = (self.used + 15) & ~15
+        if off + nbytes > self.cap:
+            if self.items:
+                raise RuntimeError("landing buffer too small (reserve() it before the first take)")
+            self.reserve(off + nbytes)
+        rt.copy_async(self.host.ctypes.data + off, t.data_ptr(), nbytes, rt.D2H)
+        self.used = off + nbytes
+        self.items.append((off, tuple(t.shape), self._NP[t.dtype]))
+        return len(self.items) - 1
+
+    def reserve(self, nbytes: int) -> None:
+        if nbytes > self.cap and self.device.type == "cuda":
+            self.cap = max(2 * nbytes, 1 << 16)
+            with torch.cuda.device(rt.indexed(self.device)):
+                self.host = rt.Arena(self.cap + 256, pinned=True).array((self.cap,), np.uint8)
+            if self.done is None:
+                self.done = rt.Event()
+
+    def mark(self) -> None:
+        if self.done is not None and self.items:
+            self.done.record()
+
+    def wait(self) -> None:
+        if self.done is not None and self.items:
+            self.done.synchronize()
+
+    def get(self, ticket: int) -> np.ndarray:
+        a, shape, dt = self.items[ticket]
+        if shape is None:
+            return a
+        n = int(np.prod(shape)) * np.dtype(dt).itemsize
+        return self.host[a:a + n].view(dt).reshape(shape)
+
+
 class Engine:
     def __init__(self, model: TransformerModel, num_kv_blocks: Optional[int] = None, block_size: int = 64,
                  max_batch_seqs: int = 256, max_prefill_tokens: int = 8192, max_model_len: int = 4096,
@@ -571,6 +632,8 @@ class Engine:
             self.last_tokens = torch.zeros(rows_cap, dtype=torch.int32, device=self.device)
         self._dec_cache = None      # (request ids, rows with decision targets) of the newest decode batch
         self._staging = _StepStaging(self.device)
+        self._landing = [_StepLanding(self.device), _StepLanding(self.device)]
+        self._cow_staging = _StepStaging(self.device)       # (source, destination) block pairs of copy-on-write
         if self.stream is not None:
             self.stream.wait_stream(torch.cuda.current_stream(self.device))   # weights were written there
         self._graphs: Dict[tuple, _DecodeGraph] = {}
@@ -695,9 +758,14 @@ class Engine:
             pass
 
     # ------------------------------------------------------------------ stepping
-    def _dev(self, a: np.ndarray, dtype=torch.int32) -> torch.Tensor:
-        # Blocking copy: the source is a temporary pageable buffer that dies with this call.
-        return torch.from_numpy(np.ascontiguousarray(a)).to(device=self.device, dtype=dtype)
+    def _copy_blocks(self, src: np.ndarray, dst: np.ndarray) -> None:
+        """Copy-on-write block copies, queued on the step's stream ahead of its kernels; the block
+        numbers reach the device through a pinned staging buffer (no blocking copy)."""
+        cs = self._cow_staging
+        cs.begin()
+        a, b = cs.put(np.asarray(src, dtype=np.int32)), cs.put(np.asarray(dst, dtype=np.int32))
+        cs.ship()
+        self.kv.copy_blocks(cs.view(a), cs.view(b))
 
     def _on_stream(self):
         return torch.cuda.stream(self.stream) if self.stream is not None else contextlib.nullcontext()
@@ -735,7 +803,7 @@ class Engine:
         t0 = time.perf_counter()
         with self._on_stream():
             if len(plan.copy_src):
-                self.kv.copy_blocks(self._dev(plan.copy_src), self._dev(plan.copy_dst))
+                self._copy_blocks(plan.copy_src, plan.copy_dst)
                 self.metrics.inc("kv.cow_copies", len(plan.copy_src))
             if plan.kind == PK.Prefill:
                 with span(f"{self.name}.prefill", "engine", tokens=len(plan.token_ids)):
@@ -763,7 +831,7 @@ class Engine:
             # reserved for it are the ones the ordinary plan reserves again.
             if len(nxt.copy_src):
                 with self._on_stream():
-                    self.kv.copy_blocks(self._dev(nxt.copy_src), self._dev(nxt.copy_dst))
+                    self._copy_blocks(nxt.copy_src, nxt.copy_dst)
             return
         self._ahead = (nxt, self.launch_step(nxt))
         self.metrics.inc("decode.ahead_steps")
@@ -830,7 +898,7 @@ class Engine:
         if n_last or n_riders:
             # logits rows: the prompts that end in this step, then the riders (the step's last rows)
             need = np.concatenate([plan.last_rows, cu[rf:n_seq]]) if n_riders else plan.last_rows
-            t_need = sg.put(np.asarray(need).astype(np.int64))
+            t_need = sg.put(np.asarray(need).astype(np.int32))
             slots = self.sched.prefill_sample_layout(plan)
             if slots or n_riders:
                 ri = [s.last_row_index for s in slots] + list(range(n_last, n_last + n_riders))
@@ -851,15 +919,28 @@ class Engine:
                           sg.put(np.array(top_k, dtype=np.int32)),
                           sg.put(np.array(seeds, dtype=np.uint64).astype(np.int64)),
                           sg.put(np.array(steps, dtype=np.int32)), sg.put(np.array(ri, dtype=np.int32)))
+        # Log-probs wanted at the last position of prompts that end here (Score requests, decision
+        # targets) and of riders with decision targets: the target ids travel with the step's
+        # inputs, the gathers are queued behind the logits, nothing of it waits for the host.
+        want = self._score_wants(plan) if t_need is not None else []
+        t_want, want_cols = None, 0
+        if want:
+            ids_w = self._padded_targets(want)
+            want_cols = ids_w.shape[1]
+            t_want = (sg.put(np.array([j for j, _, _ in want], dtype=np.int32)), sg.put(ids_w))
+        rider_dec = None
+        if n_riders:
+            r_req = np.array(req_ids[rf:], copy=True)
+            dec = [self._reqs[int(r)].decision_ids for r in r_req]
+            if any(dec):
+                ids_h = np.zeros((len(dec), self.max_decision), dtype=np.int32)
+                for i, d in enumerate(dec):
+                    if d:
+                        ids_h[i, : len(d)] = d
+                rider_dec = (r_req, sg.put(np.arange(n_last, n_last + len(dec), dtype=np.int32)), sg.put(ids_h))
         # A sharded model whose step only scores (nothing samples, no riders) exchanges the target
         # log-probs instead of all-gathering the logits rows.
-        t_score = None
-        if t_need is not None and t_samp is None and m.tp_size > 1:
-            want = self._score_wants(plan)
-            if want:
-                ids_h = self._padded_targets(want)
-                t_score = (want, sg.put(np.array([plan.last_rows[j] for j, _, _ in want], dtype=np.int64)),
-                           sg.put(ids_h))
+        score_only = bool(want) and t_samp is None and m.tp_size > 1
         sg.ship()
         bt, ctx = sg.view(t_bt), sg.view(t_ctx)
         if n_riders:
@@ -878,17 +959,34 @@ class Engine:
             sums = ops.embed_pool_ranges(hidden, sg.view(t_eb), sg.view(t_ee), mode=2)
             for j, i in enumerate(emb):
                 st = self._reqs[int(req_ids[i])]
-                st.embed_sum = sums[j] if st.embed_sum is None else st.embed_sum + sums[j]
+                if st.embed_sum is None:
+                    st.embed_sum = sums[j]
+                else:
+                    ops.accumulate_(st.embed_sum, sums[j])
                 st.embed_count += int(cu[i + 1] - cu[i])
-        toks = lps = logits = scored = None
-        if t_score is not None:
-            self.metrics.inc("prefill.target_only_score_rows", len(t_score[0]))
-            scored = (t_score[0], m.target_logprobs(hidden[sg.view(t_score[1])], sg.view(t_score[2])))
-        elif t_need is not None:
-            logits = m.logits(hidden[sg.view(t_need)])
-            if t_samp is not None:
-                toks, lps = ops.sample(logits, *(sg.view(t) for t in t_samp))
-        return toks, lps, logits, scored
+        land = self._landing[self._step_no & 1]
+        land.begin()
+        k_tok = k_lp = k_want = k_rdec = None
+        if t_need is not None:
+            rows = ops.gather_rows(hidden, sg.view(t_need))
+            if score_only:
+                self.metrics.inc("prefill.target_only_score_rows", len(want))
+                vals = m.target_logprobs(ops.gather_rows(rows, sg.view(t_want[0])), sg.view(t_want[1]))
+                land.reserve(vals.numel() * 4 + 64)
+                k_want = land.take(vals)
+            else:
+                logits = m.logits(rows)
+                n_out = (len(slots) + n_riders) if t_samp is not None else 0
+                land.reserve(8 * n_out + 4 * (want_cols * len(want) + self.max_decision * n_riders) + 256)
+                if t_samp is not None:
+                    toks, lps = ops.sample(logits, *(sg.view(t) for t in t_samp))
+                    k_tok, k_lp = land.take(toks), land.take(lps)
+                if want:
+                    k_want = land.take(ops.logprob_gather(logits, sg.view(t_want[1]), sg.view(t_want[0])))
+                if rider_dec is not None:
+                    k_rdec = land.take(ops.logprob_gather(logits, sg.view(rider_dec[2]), sg.view(rider_dec[1])))
+        land.mark()
+        return land, k_tok, k_lp, (want, k_want), (rider_dec[0] if rider_dec is not None else None, k_rdec)
 
     def _score_wants(self, plan) -> list:
         """(index into the step's last rows, request state, target ids) of every prompt that ends
@@ -920,39 +1018,20 @@ class Engine:
                     st.decisions[st.seed + k] = v
 
     def _prefill_finish(self, plan, state) -> None:
-        toks, lps, logits, scored = state
-        req_ids = plan.request_ids
+        land, k_tok, k_lp, (want, k_want), (r_req, k_rdec) = state
+        land.wait()                       # the one wait for everything this step sends back
         first_tokens = np.zeros(0, dtype=np.int32)
         first_lps = np.zeros(0, dtype=np.float32)
-        if toks is not None:
-            first_tokens, first_lps = toks.cpu().numpy(), lps.cpu().numpy()
-        if scored is not None:
-            self._store_scores(scored[0], scored[1].cpu().numpy())
-        if logits is not None:
-            # decisions / scores at the prompt's last position: one gather over all rows that
-            # need one (target lists padded to a common width), one read-back
-            want = self._score_wants(plan)
-            if want:
-                rows = self._dev(np.array([j for j, _, _ in want], dtype=np.int32))
-                vals = ops.logprob_gather(logits, self._dev(self._padded_targets(want)), rows).cpu().numpy()
-                self._store_scores(want, vals)
-            rf = plan.rider_first
-            if rf >= 0:
-                # Riders with decision targets: same bookkeeping as a decode step (the newest row
-                # block is kept, rows are resolved when their chain leaves the batch).
-                r_req = np.array(req_ids[rf:], copy=True)
-                dec = [self._reqs[int(r)].decision_ids for r in r_req]
-                if any(dec):
-                    ids_h = np.zeros((len(dec), self.max_decision), dtype=np.int32)
-                    for i, d in enumerate(dec):
-                        if d:
-                            ids_h[i, : len(d)] = d
-                    n_last = len(plan.last_rows)
-                    rows = self._dev(np.arange(n_last, n_last + len(dec), dtype=np.int32))
-                    vals = ops.logprob_gather(logits, self._dev(ids_h), rows).cpu().numpy()
-                    cur = (r_req, np.array(plan.seeds, copy=True), vals)
-                    self._flush_decisions(keep=cur)
-                    self._last_dec = cur
+        if k_tok is not None:
+            first_tokens, first_lps = np.array(land.get(k_tok), copy=True), np.array(land.get(k_lp), copy=True)
+        if k_want is not None:
+            self._store_scores(want, land.get(k_want))
+        if k_rdec is not None:
+            # Riders with decision targets: same bookkeeping as a decode step (the newest row
+            # block is kept, rows are resolved when their chain leaves the batch).
+            cur = (r_req, np.array(plan.seeds, copy=True), np.array(land.get(k_rdec), copy=True))
+            self._flush_decisions(keep=cur)
+            self._last_dec = cur
         self.sched.complete_prefill(plan, first_tokens.astype(np.int32), first_lps.astype(np.float32))
 
     def _bucket(self, B: int) -> int:

@@ -176,14 +176,9 @@ class TransformerModel:
             self.layers.append(lw)
 
     def decode_capturable(self, rows: int) -> bool:
-        """Whether a decode step of ``rows`` sequences can be recorded into a hipGraph. The only
-        step that cannot is an expert-parallel all-to-all step whose per-rank share of routed rows
-        exceeds the fixed-capacity exchange (parallel/ep.py): it sizes its buffers from a count it
-        reads back from the device."""
-        if self.ep_size > 1 and self.ep_mode == "a2a" and self.cfg.is_moe:
-            from ..parallel.ep import EP_FIXED_MAX_ROWS
-
-            return -(-rows // self.ep_size) * self.cfg.experts_per_tok <= EP_FIXED_MAX_ROWS
+        """Whether a decode step of ``rows`` sequences can be recorded into a hipGraph: every
+        model family's step is made of kernel launches with host-known shapes only (the
+        expert-parallel exchange carries its row counts on the device, parallel/ep.py)."""
         return True
 
     @classmethod
@@ -285,7 +280,7 @@ class TransformerModel:
         if self.tp_size > 1:
             vshard = (self.cfg.vocab_size + self.tp_size - 1) // self.tp_size
             if lg.shape[1] < vshard:  # ragged last shard: equal-sized parts for the all-gather
-                lg = torch.nn.functional.pad(lg, (0, vshard - lg.shape[1]), value=float("-inf"))
+                lg = ops.pad_cols(lg, vshard, float("-inf"))
             lg = self.comm.all_gather_cols(lg, self.cfg.vocab_size)
         return lg
 
@@ -297,17 +292,12 @@ class TransformerModel:
         nothing else: the judge of the reference reads one verdict per answer,
         /root/reference/src/main.rs:259-291)."""
         lg = ops.linear(hidden_rows, self.lm_head, out_f32=True)
-        ids = ids.long()
         if self.tp_size == 1:
-            return lg.gather(1, ids) - torch.logsumexp(lg, dim=-1, keepdim=True)
+            return ops.logprob_gather(lg, ids)
         vshard = (self.cfg.vocab_size + self.tp_size - 1) // self.tp_size
-        local = ids - self.tp_rank * vshard
-        mine = (local >= 0) & (local < lg.shape[1])
-        vals = torch.where(mine, lg.gather(1, local.clamp(0, lg.shape[1] - 1)), torch.zeros((), dtype=lg.dtype, device=lg.device))
-        packed = torch.cat([vals, torch.logsumexp(lg, dim=-1, keepdim=True)], dim=1)       # [R, C + 1]
+        packed = ops.logit_targets_shard(lg, ids, self.tp_rank * vshard)          # [R, Cp]: targets, lse, padding
         parts = self.comm.all_gather_rows(packed).view(self.tp_size, *packed.shape)
-        C = ids.shape[1]
-        return parts[:, :, :C].sum(0) - torch.logsumexp(parts[:, :, C], dim=0).unsqueeze(1)
+        return ops.logprob_merge(parts, ids.shape[-1])
 
 
 def hf_param_shape(cfg: ModelConfig, name: str) -> Tuple[int, ...]:

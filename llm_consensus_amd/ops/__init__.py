@@ -545,6 +545,90 @@ def logprob_gather(logits, ids, row_index=None) -> torch.Tensor:
     return out
 
 
+def logit_targets_shard(logits, ids, vocab_lo: int, row_index=None) -> torch.Tensor:
+    """One vocabulary shard's share of ``logprob_gather``: fp32 [R, Cp] with the raw logits of the
+    targets that fall into columns [vocab_lo, vocab_lo + V_local) (0 elsewhere) in columns
+    [0, C), the shard's log-sum-exp in column C and zero padding up to Cp = C + 1 rounded up to
+    four floats (whole 16-byte rows for the exchange). ``logprob_merge`` combines the shards."""
+    C = ids.shape[-1]
+    Cp = (C + 1 + 3) // 4 * 4
+    R = row_index.numel() if row_index is not None else logits.shape[0]
+    if not logits.is_cuda:
+        rows = logits[row_index.long()] if row_index is not None else logits
+        local = ids.long() - vocab_lo
+        local = local.expand(R, C) if local.dim() == 2 else local.view(1, C).expand(R, C)
+        mine = (local >= 0) & (local < rows.shape[1])
+        out = torch.zeros(R, Cp, dtype=torch.float32)
+        out[:, :C] = torch.where(mine, rows.gather(1, local.clamp(0, rows.shape[1] - 1)), torch.zeros(()))
+        out[:, C] = torch.logsumexp(rows.float(), dim=-1)
+        return out
+    h = _hip()
+    out = torch.empty(R, Cp, dtype=torch.float32, device=logits.device)
+    h.call("lc_logit_targets_shard", logits.data_ptr(), logits.shape[1], logits.stride(0), h.ptr(row_index),
+           ids.data_ptr(), C if ids.dim() == 2 else 0, C, Cp, int(vocab_lo), out.data_ptr(), R)
+    return out
+
+
+def logprob_merge(parts: torch.Tensor, C: int) -> torch.Tensor:
+    """parts fp32 [W, R, Cp] (``logit_targets_shard`` of W vocabulary shards) -> log-softmax values
+    of the targets, fp32 [R, C]."""
+    W, R, Cp = parts.shape
+    if not parts.is_cuda:
+        return parts[:, :, :C].sum(0) - torch.logsumexp(parts[:, :, C], dim=0).unsqueeze(1)
+    h = _hip()
+    parts = parts.contiguous()
+    out = torch.empty(R, C, dtype=torch.float32, device=parts.device)
+    h.call("lc_logprob_merge", parts.data_ptr(), W, R, C, Cp, out.data_ptr())
+    return out
+
+
+def accumulate_(y: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
+    """y += x for fp32 tensors of one shape (in place)."""
+    if not y.is_cuda:
+        return y.add_(x)
+    h = _hip()
+    h.call("lc_accumulate_f32", y.data_ptr(), x.contiguous().data_ptr(), y.numel())
+    return y
+
+
+def pad_cols(x: torch.Tensor, n_pad: int, fill: float) -> torch.Tensor:
+    """fp32 [R, n] -> [R, n_pad] with ``fill`` in the new columns."""
+    R, n = x.shape
+    if n == n_pad:
+        return x
+    if not x.is_cuda:
+        return torch.nn.functional.pad(x, (0, n_pad - n), value=fill)
+    h = _hip()
+    out = torch.empty(R, n_pad, dtype=torch.float32, device=x.device)
+    h.call("lc_pad_cols_f32", x.contiguous().data_ptr(), out.data_ptr(), R, n, n_pad, float(fill))
+    return out
+
+
+def concat_cols(parts: torch.Tensor, total_cols: Optional[int] = None) -> torch.Tensor:
+    """[W, R, c] -> [R, W * c] (the W blocks side by side), cut to ``total_cols`` columns."""
+    W, R, c = parts.shape
+    total = W * c if total_cols is None else int(total_cols)
+    if not parts.is_cuda:
+        return parts.permute(1, 0, 2).reshape(R, W * c)[:, :total]
+    es = parts.element_size()
+    if es % 2:
+        raise ValueError("concat_cols needs elements of 2 or 4 bytes")
+    h = _hip()
+    parts = parts.contiguous()
+    out = torch.empty(R, total, dtype=parts.dtype, device=parts.device)
+    u = es // 2
+    h.call("lc_concat_cols", parts.data_ptr(), W, R, c * u, total * u, out.data_ptr())
+    return out
+
+
+def gather_rows(x: torch.Tensor, rows: torch.Tensor) -> torch.Tensor:
+    """x[rows] for a bf16 matrix and int32 row numbers (the embedding-gather kernel: a row
+    gather is what it is)."""
+    if not x.is_cuda:
+        return x[rows.long()]
+    return embed(rows, x)
+
+
 # ---------------------------------------------------------------------------- MoE
 @dataclass
 class ExpertWeights:
@@ -660,15 +744,19 @@ def experts_on_sorted(x: torch.Tensor, row_index: Optional[torch.Tensor], offset
     return y
 
 
-def moe_combine(y: torch.Tensor, slot_of: torch.Tensor, wts: torch.Tensor, T: int) -> torch.Tensor:
-    """out[t] = sum_k wts[t, k] * y[slot_of[t*k + j]] (fp32 accumulation, activation dtype out)."""
+def moe_combine(y: torch.Tensor, slot_of: torch.Tensor, wts: torch.Tensor, T: int,
+                out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out[t] = sum_k wts[t, k] * y[slot_of[t*k + j]] (fp32 accumulation, activation dtype out;
+    written into ``out``, T contiguous rows, when given)."""
     topk = wts.shape[1]
     d = y.shape[1]
     if not y.is_cuda:
         rows = y[slot_of.long()].float().view(T, topk, d)
-        return (rows * wts.float()[:, :, None]).sum(1).to(y.dtype)
+        res = (rows * wts.float()[:, :, None]).sum(1).to(y.dtype)
+        return res if out is None else out.copy_(res)
     h = _hip()
-    out = torch.empty(T, d, dtype=y.dtype, device=y.device)
+    if out is None:
+        out = torch.empty(T, d, dtype=y.dtype, device=y.device)
     h.call("lc_moe_combine", y.data_ptr(), slot_of.data_ptr(), wts.data_ptr(), out.data_ptr(), T, d, topk)
     return out
 

@@ -44,6 +44,11 @@ _SIGNATURES = {
     "lc_fill_f32": [_P, _F, _L, _P],
     "lc_sample": [_P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P],
     "lc_logprob_gather": [_P, _I, _I, _P, _P, _I, _I, _P, _I, _P],
+    "lc_logit_targets_shard": [_P, _I, _I, _P, _P, _I, _I, _I, _I, _P, _I, _P],
+    "lc_logprob_merge": [_P, _I, _I, _I, _I, _P, _P],
+    "lc_accumulate_f32": [_P, _P, _L, _P],
+    "lc_concat_cols": [_P, _I, _I, _I, _I, _P, _P],
+    "lc_pad_cols_f32": [_P, _P, _I, _I, _I, _F, _P],
     "lc_majority_vote": [_P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P],
     "lc_cosine_medoid": [_P, _I, _I, _I, _L, _P, _P, _P, _P],
     "lc_judge_reduce": [_P, _I, _I, _I, _P, _P, _P, _P],

@@ -50,6 +50,20 @@ class Comm:
         block r goes to rank r; the result's block s is what rank s sent here."""
         return t
 
+    def all_to_all_counted(self, t: torch.Tensor, counts: torch.Tensor, per: int):
+        """All-to-all of row blocks of which only a counted prefix exists: ``t`` is ``world``
+        blocks of equal height, block r bound for rank r; ``counts`` (int32 [world * per], on
+        ``t``'s device) says per destination, in ``per`` slots, how many of its rows are real.
+        Returns (received blocks, received counts): entry s * per + e of the latter is what rank
+        s reported for (this rank, slot e). This default moves the whole blocks with two
+        equal-split exchanges; communicators that can read the counts on the device move only the
+        rows that exist (parallel/p2p.py)."""
+        return self.all_to_all_equal(t), self.all_to_all_equal(counts)
+
+    def counted_rows_cap(self, row_bytes: int) -> int:
+        """Most rows per (source, destination) pair one all_to_all_counted call can carry."""
+        return 1 << 30
+
     def barrier(self) -> None:
         pass
 

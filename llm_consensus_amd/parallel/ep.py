@@ -16,14 +16,15 @@ schemes produce the replicated FFN output:
 ``a2a``        each rank takes a 1/ep slice of the tokens, routes it, sends every
                (token, k) row to the expert's owner with all-to-all, receives the MLP
                outputs back the same way, combines, and the slices are all-gathered.
-               Every (source, destination) pair owns a fixed number of rows (``cap``) of
-               the exchange buffers, so all three exchanges have equal splits and the
-               per-expert row counts travel as data: up to EP_FIXED_MAX_ROWS routed rows
-               per rank (decode steps) cap is the worst case and nothing waits for the
-               host; above that (prefill chunks) the ranks agree on the largest actual
-               count first, which costs one device->host read per layer and keeps the
-               buffers close to the T/ep*k*d bytes a rank really has to send. No rank
-               multiplies rows for experts it does not own.
+               Every (source, destination) pair owns a fixed number of rows (``cap``, the
+               worst case: all pairs of a chunk bound for one rank) of the exchange
+               buffers, and the per-expert row counts travel as data next to the rows
+               (``Comm.all_to_all_counted``): the peer-to-peer communicator reads them on
+               the device and moves only the rows that exist, so the worst-case capacity
+               costs address space, not traffic. A slice too long for one exchange is cut
+               into chunks of EP_CHUNK_ROWS routed rows. Nothing in a layer waits for the
+               host at any size: prefill chunks and decode steps alike are plain kernel
+               launches. No rank multiplies rows for experts it does not own.
 
 On xGMI all-to-all maps to direct peer writes over the point-to-point links (every pair of
 GPUs in a node has its own link), which is the collective this fabric is best at.
@@ -52,9 +53,28 @@ def moe_allreduce(x, Wr, w_gate_up, w_down, topk: int, comm: Comm, expert_lo: in
     return out
 
 
-# Routed rows per rank (tokens/ep * top-k) up to which the exchange buffers are sized for the
-# worst case (every pair of a rank bound for one destination) instead of the measured maximum.
-EP_FIXED_MAX_ROWS = int(os.environ.get("LC_EP_FIXED_ROWS", "256"))
+# Most routed rows (tokens * top-k) of a rank's slice that go into one exchange; the buffers of an
+# exchange hold ep times as many rows (the worst case per destination). Also bounded by what the
+# communicator's staging slot carries.
+EP_CHUNK_ROWS = int(os.environ.get("LC_EP_CHUNK_ROWS", "1024"))
+
+_zero_counts: dict = {}
+
+
+def _zeros_i32(n: int, device) -> torch.Tensor:
+    """A cached int32 zero vector (the count table of a rank that has no rows in a chunk)."""
+    key = (str(device), n)
+    z = _zero_counts.get(key)
+    if z is None:
+        z = torch.empty(n, dtype=torch.int32, device=device)
+        if z.is_cuda:
+            from ..ops import hip
+
+            hip.call("lc_fill_f32", z.data_ptr(), 0.0, n)        # all-zero bits are the integer 0 too
+        else:
+            z.zero_()
+        _zero_counts[key] = z
+    return z
 
 
 def moe_all_to_all(x, Wr, w_gate_up, w_down, topk: int, comm: Comm, expert_lo: int) -> torch.Tensor:
@@ -62,29 +82,32 @@ def moe_all_to_all(x, Wr, w_gate_up, w_down, topk: int, comm: Comm, expert_lo: i
     ep, r = comm.world, comm.rank
     E = Wr.shape[0]
     per = E // ep
-    # ---- this rank's token slice, padded with zero rows to the common slice length
-    tl = (T + ep - 1) // ep
-    lo, hi = min(T, r * tl), min(T, (r + 1) * tl)
-    xs = x[lo:hi]
-    if hi - lo < tl:
-        xs = torch.cat([xs, x.new_zeros(tl - (hi - lo), d)], 0)
-    xs = xs.contiguous()
-    ids, wts = ops.moe_route(xs, Wr, topk)
-    offsets, sorted_src, slot_of = ops.moe_permute(ids, E)       # expert order == destination order
-    A = tl * topk
-    if A <= EP_FIXED_MAX_ROWS:
-        cap = A
-    else:
-        off = offsets[::per].to(torch.int64)                      # [ep + 1] destination boundaries
-        most = comm.all_gather_rows((off[1:] - off[:-1]).max().view(1, 1))
-        cap = max(64, -(-int(most.max().item()) // 64) * 64)      # the one host read of this layer
-    send, send_counts, slot_back = ops.ep_pack(xs, sorted_src, offsets, slot_of, per, ep, cap)
-    recv = comm.all_to_all_equal(send)                            # [ep*cap, d]: block s came from rank s
-    recv_counts = comm.all_to_all_equal(send_counts)              # [ep*per]
-    row_index, off_local = ops.ep_recv_index(recv_counts, ep, per, cap)
-    y = ops.experts_on_sorted(recv, row_index, off_local, 0, w_gate_up, w_down, ep * cap)
-    back = comm.all_to_all_equal(ops.scatter_rows(y, row_index, off_local[per:]))
-    out = ops.moe_combine(back, slot_back, wts, tl)
+    tl = (T + ep - 1) // ep                      # slice length, the same on every rank
+    lo = min(T, r * tl)
+    n = min(T, (r + 1) * tl) - lo                # rows of the slice that exist on this rank
+    # Rows [n, tl) of a short last slice are never written: after the gather they lie beyond T.
+    out = torch.empty(tl, d, dtype=x.dtype, device=x.device)
+    rows_cap = max(topk, min(EP_CHUNK_ROWS, comm.counted_rows_cap(d * x.element_size())))
+    ct = max(1, rows_cap // topk)                # tokens per chunk
+    for c0 in range(0, tl, ct):
+        c1 = min(tl, c0 + ct)
+        cap = (c1 - c0) * topk                   # every pair's share of the buffers (same on all ranks)
+        m = max(0, min(n, c1) - c0)              # this rank's tokens in the chunk
+        if m > 0:
+            xs = x[lo + c0: lo + c0 + m]
+            ids, wts = ops.moe_route(xs, Wr, topk)
+            offsets, sorted_src, slot_of = ops.moe_permute(ids, E)   # expert order == destination order
+            send, send_counts, slot_back = ops.ep_pack(xs, sorted_src, offsets, slot_of, per, ep, cap)
+        else:
+            send = torch.empty(ep * cap, d, dtype=x.dtype, device=x.device)
+            send_counts = _zeros_i32(ep * per, x.device)
+        recv, recv_counts = comm.all_to_all_counted(send, send_counts, per)     # block s came from rank s
+        row_index, off_local = ops.ep_recv_index(recv_counts, ep, per, cap)
+        y = ops.experts_on_sorted(recv, row_index, off_local, 0, w_gate_up, w_down, ep * cap)
+        # way back: to every source exactly the rows it sent, in its order
+        back, _ = comm.all_to_all_counted(ops.scatter_rows(y, row_index, off_local[per:]), recv_counts, per)
+        if m > 0:
+            ops.moe_combine(back, slot_back, wts, m, out=out[c0:c0 + m])
     full = comm.all_gather_rows(out)
     return full[:T] if ep * tl != T else full
 

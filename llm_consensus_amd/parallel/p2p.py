@@ -52,11 +52,15 @@ def _L():
         l.lc_p2p_comm_error.argtypes, l.lc_p2p_comm_error.restype = [c_void_p], c_int
         l.lc_p2p_comm_capacity.argtypes, l.lc_p2p_comm_capacity.restype = [c_void_p], c_longlong
         l.lc_p2p_comm_set_timeout.argtypes, l.lc_p2p_comm_set_timeout.restype = [c_void_p, c_double], None
-        l.lc_p2p_allreduce.argtypes = [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
-                                       c_float, c_int, c_int, c_void_p]
+        l.lc_p2p_allreduce.argtypes = [c_void_p, c_void_p, c_int, c_longlong, c_void_p, c_void_p, c_void_p, c_void_p,
+                                       c_int, c_int, c_float, c_int, c_int, c_void_p]
         l.lc_p2p_allreduce.restype = c_int
         l.lc_p2p_exchange.argtypes = [c_void_p, c_void_p, c_void_p, c_longlong, c_int, c_int, c_void_p]
         l.lc_p2p_exchange.restype = c_int
+        l.lc_p2p_counted_cap.argtypes, l.lc_p2p_counted_cap.restype = [c_void_p, c_longlong], c_longlong
+        l.lc_p2p_exchange_counted.argtypes = [c_void_p, c_void_p, c_void_p, c_longlong, c_int, c_void_p, c_int, c_void_p,
+                                              c_void_p]
+        l.lc_p2p_exchange_counted.restype = c_int
         _lib = l
     return _lib
 
@@ -264,14 +268,12 @@ class P2PComm(Comm):
         for r0 in range(0, T, rows_cap):           # same split on every rank: capacity and shapes are equal
             n = min(rows_cap, T - r0)
             two = 1 if (n * d * 2 > TWO_SHOT_BYTES and not self.publish_only) else 0
-            if part is not None and rows_cap < T:
-                # slabs of a row range are not contiguous across S: sum this range first
-                xr, pr = part[:, r0:r0 + n].sum(0).to(torch.bfloat16).contiguous(), None
-            else:
-                xr, pr = (xin[r0:r0 + n] if xin is not None else None), part
+            xr = xin[r0:r0 + n] if xin is not None else None
+            # a row range of the slab stack: same slabs, first row r0, slabs still T * d apart
+            pp = part.data_ptr() + 4 * r0 * d if part is not None else None
             rc = l.lc_p2p_allreduce(
-                self._h, pr.data_ptr() if pr is not None else None, S if pr is not None else 0,
-                xr.data_ptr() if xr is not None else None, h[r0:r0 + n].data_ptr() if h is not None else None,
+                self._h, pp, S, T * d, xr.data_ptr() if xr is not None else None,
+                h[r0:r0 + n].data_ptr() if h is not None else None,
                 w.data_ptr() if w is not None else None, y[r0:r0 + n].data_ptr(), n, d, float(eps), two,
                 1 if self.publish_only else 0, self._stream())
             self._check(rc, "lc_p2p_allreduce")
@@ -304,31 +306,23 @@ class P2PComm(Comm):
     # ------------------------------------------------------------------ byte exchanges
     def _exchange(self, src: torch.Tensor, all_to_all: bool) -> Optional[torch.Tensor]:
         """Returns [world, ...block shape], or None when the message is not a device tensor or
-        does not fit the staging slot. Blocks that are not a multiple of 16 bytes are padded
-        (a copy on the device; the exchange stays one launch and stays capturable)."""
+        does not fit the staging slot. Blocks of any byte length travel in one launch (the
+        kernel has a narrow path for lengths that are not a multiple of 16)."""
         src = src.contiguous()
         nbytes = src.numel() * src.element_size()
         nblk = self.world if all_to_all else 1
         m = nbytes // nblk
         if not src.is_cuda or m == 0 or nbytes % nblk:
             return None
-        m_pad = (m + 15) // 16 * 16
-        if m_pad * nblk > self.capacity:
+        if (m + 15) // 16 * 16 * nblk > self.capacity:
             return None
         block_shape = ((src.shape[0] // self.world,) + tuple(src.shape[1:])) if all_to_all else tuple(src.shape)
-        raw = src.view(torch.uint8).view(nblk, m)
-        if m_pad != m:
-            padded = torch.zeros(nblk, m_pad, dtype=torch.uint8, device=src.device)
-            padded[:, :m] = raw
-            raw = padded
-        out = torch.empty(self.world, m_pad, dtype=torch.uint8, device=src.device)
-        rc = _L().lc_p2p_exchange(self._h, raw.data_ptr(), out.data_ptr(), m_pad, 1 if all_to_all else 0,
+        out = torch.empty((self.world,) + block_shape, dtype=src.dtype, device=src.device)
+        rc = _L().lc_p2p_exchange(self._h, src.data_ptr(), out.data_ptr(), m, 1 if all_to_all else 0,
                                   1 if self.publish_only else 0, self._stream())
         self._check(rc, "lc_p2p_exchange")
         self.calls += 1
-        if m_pad != m:
-            out = out[:, :m].contiguous()
-        return out.view(src.dtype).view((self.world,) + block_shape)
+        return out
 
     def all_gather_rows(self, t: torch.Tensor) -> torch.Tensor:
         out = self._exchange(t, False)
@@ -340,16 +334,42 @@ class P2PComm(Comm):
         out = self._exchange(t, False)
         if out is None:
             return self.base.all_gather_cols(t, total_cols)
-        # [W, ..., c] -> [..., W*c]
-        nd = out.dim()
-        res = out.permute(*range(1, nd - 1), 0, nd - 1).reshape(tuple(t.shape[:-1]) + (self.world * t.shape[-1],))
-        return res[..., :total_cols] if total_cols is not None else res
+        # [W, ..., c] -> [..., W*c], one launch
+        from .. import ops
+
+        lead = tuple(t.shape[:-1])
+        res = ops.concat_cols(out.view(self.world, -1, t.shape[-1]), total_cols)
+        return res.view(lead + (res.shape[-1],))
 
     def all_to_all_equal(self, t: torch.Tensor) -> torch.Tensor:
         out = self._exchange(t, True) if t.shape[0] % self.world == 0 else None
         if out is None:
             return self.base.all_to_all_equal(t)
         return out.view(t.shape)
+
+    def counted_rows_cap(self, row_bytes: int) -> int:
+        return int(_L().lc_p2p_counted_cap(self._h, row_bytes))
+
+    def all_to_all_counted(self, t: torch.Tensor, counts: torch.Tensor, per: int):
+        """``t`` [world * cap, d]: block r holds the rows bound for rank r, of which only the
+        first sum(counts[r * per : (r + 1) * per]) exist (``counts`` int32 [world * per] on the
+        device). Returns (received [world * cap, d], recv_counts int32 [world * per]): block s
+        holds what rank s sent here, rows beyond its count are unspecified. Only rows that exist
+        cross the fabric, and the host never learns the counts."""
+        W = self.world
+        cap = t.shape[0] // W
+        row_bytes = t.shape[1] * t.element_size()
+        if (not t.is_cuda or t.shape[0] % W or row_bytes % 16 or W * per * 4 > 4096
+                or cap > self.counted_rows_cap(row_bytes)):
+            return super().all_to_all_counted(t, counts, per)
+        t, counts = t.contiguous(), counts.contiguous()
+        out = torch.empty_like(t)
+        recv_counts = torch.empty_like(counts)
+        rc = _L().lc_p2p_exchange_counted(self._h, t.data_ptr(), out.data_ptr(), row_bytes, cap, counts.data_ptr(), per,
+                                          recv_counts.data_ptr(), self._stream())
+        self._check(rc, "lc_p2p_exchange_counted")
+        self.calls += 1
+        return out, recv_counts
 
     # ------------------------------------------------------------------ everything else
     def broadcast(self, t, src=0):

@@ -151,6 +151,26 @@ def main() -> None:
     one = comm.all_gather_rows(torch.tensor([[rank]], dtype=torch.int64, device=DEV))
     assert one.view(-1).cpu().tolist() == list(range(W))
 
+    # ---- counted all-to-all: only the rows that exist move, the counts travel on the device
+    cap, per, dd = 6, 2, 64
+    rows = torch.zeros(W * cap, dd, dtype=torch.bfloat16)
+    counts = torch.zeros(W * per, dtype=torch.int32)
+    for t in range(W):
+        n_t = (rank + 2 * t) % (cap + 1)                       # rows this rank sends to rank t
+        counts[t * per], counts[t * per + 1] = n_t // 2, n_t - n_t // 2
+        rows[t * cap: t * cap + n_t] = (torch.arange(n_t).view(-1, 1) + 10 * t + 100 * rank).to(torch.bfloat16)
+    sentinel = torch.full((W * cap, dd), -7.0, dtype=torch.bfloat16, device=DEV)
+    got, got_counts = comm.all_to_all_counted(rows.to(DEV), counts.to(DEV), per)
+    assert got.shape == (W * cap, dd) and got_counts.shape == (W * per,)
+    for s_ in range(W):
+        n_s = (s_ + 2 * rank) % (cap + 1)                      # rows rank s_ sent here
+        assert got_counts[s_ * per: (s_ + 1) * per].cpu().tolist() == [n_s // 2, n_s - n_s // 2]
+        want_rows = (torch.arange(n_s).view(-1, 1) + 10 * rank + 100 * s_).to(torch.bfloat16).expand(n_s, dd)
+        assert torch.equal(got[s_ * cap: s_ * cap + n_s].cpu(), want_rows), (s_, n_s)
+    del sentinel
+    odd7 = comm.all_gather_rows(torch.arange(7, dtype=torch.uint8, device=DEV).view(1, 7) + rank)   # 7-byte blocks
+    assert odd7.cpu().tolist() == [[(j + s_) for j in range(7)] for s_ in range(W)]
+
     progress("messages larger")
     # ---- messages larger than the staging slot are cut into row ranges
     small = p2p.P2PComm(base, DEV, stage_bytes=64 << 10, timeout_s=5, grid_cap=32)
@@ -249,6 +269,19 @@ def main() -> None:
         assert eng.metrics.counter("prefill.target_only_score_rows") == 1
         only = np.array(eng.pop_result(r).scores)
         assert np.allclose(only, want_scores, atol=0.06), (only, want_scores)
+        # eager steps of the sharded model (prefill + score exchange, prefill + sample, decode with
+        # the fused all-reduce, the logits all-gather): PyTorch launches no kernel of its own
+        from llm_consensus_amd.utils.audit import AtenAudit
+
+        eager = Engine(tp, num_kv_blocks=64, block_size=64, use_graphs=False)
+        for _ in range(2):                      # the second pass is the audited one (lazy initialisation is over)
+            with AtenAudit() as audit:
+                r1 = eager.submit(prompt, core.RequestKind.Score, score_ids=targets)
+                r2 = eager.submit(prompt[:40], core.RequestKind.Generate, 1, sp)
+                eager.run_until_done()
+                torch.cuda.synchronize()
+            eager.pop_result(r1), eager.pop_result(r2)
+        assert audit.kernels == {}, f"TP steps launched PyTorch kernels: {audit.kernels}"
         # the bootstrap communicator alone cannot be captured: asking for graphs is an error, not a crash
         plain = TransformerModel.random_init(cfg, DEV, seed=6, std=0.05, tp_rank=rank, tp_size=W, comm=base)
         try:
@@ -281,6 +314,26 @@ def main() -> None:
             assert np.allclose(got_scores, want_scores, atol=0.06), (mode, got_scores, want_scores)
             toks = base.all_gather_object(list(got_toks))
             assert all(t == toks[0] for t in toks), mode
+            from llm_consensus_amd.utils.audit import AtenAudit
+
+            eager = Engine(m, num_kv_blocks=64, block_size=64, use_graphs=False)
+            for _ in range(2):
+                with AtenAudit() as audit:
+                    r1 = eager.submit(prompt, core.RequestKind.Score, score_ids=targets)
+                    r2 = eager.submit(prompt[:30], core.RequestKind.Generate, 1, sp)
+                    eager.run_until_done()
+                    torch.cuda.synchronize()
+                eager.pop_result(r1), eager.pop_result(r2)
+            assert audit.kernels == {}, f"EP {mode} steps launched PyTorch kernels: {audit.kernels}"
+        comm.check()
+        # a slice longer than one exchange carries: several counted exchanges per layer, same result
+        from llm_consensus_amd.parallel import ep as ep_mod
+
+        ep_mod.EP_CHUNK_ROWS = 8
+        m = TransformerModel.random_init(mcfg, DEV, seed=5, std=0.08, comm=comm, ep_size=W, ep_mode="a2a")
+        got_scores, _, _ = run_moe(m)
+        assert np.allclose(got_scores, want_scores, atol=0.06), ("chunked a2a", got_scores, want_scores)
+        ep_mod.EP_CHUNK_ROWS = 1024
         comm.check()
 
     progress("all checks passed")

@@ -388,3 +388,49 @@ def test_one_layer_at_real_model_shapes_against_the_cpu_oracle(preset):
     for name, a, b in zip(("prefill hidden", "decode hidden", "decode logits"), got, want):
         err = float((a - b).norm() / b.norm())
         assert err <= 1e-2, (preset, name, err)
+
+
+def test_serving_steps_launch_only_the_kernel_library():
+    """Prefill (with prompts ending, scores and decisions wanted), mixed steps, decode steps,
+    embedding steps and the vote reducer of a three-model ensemble: PyTorch launches no kernel
+    of its own in any of them (AtenAudit sees every aten operator that touches a CUDA tensor;
+    allocations, views and plain buffer copies aside, there must be none). Run eagerly, so that
+    every step really goes through the op layer (a replayed hipGraph calls nothing at all)."""
+    from llm_consensus_amd.consensus.backend import GenParams
+    from llm_consensus_amd.consensus.members import Member
+    from llm_consensus_amd.consensus.strategies import MajorityVote
+    from llm_consensus_amd.engine.backend import EngineBackend
+    from llm_consensus_amd.utils.audit import AtenAudit
+    from llm_consensus_amd.utils.tokenizer import ByteLevelTokenizer
+
+    engines, members = [], []
+    for i, name in enumerate(("small-llama", "tiny-qwen", "tiny-mixtral")):
+        m = TransformerModel.random_init(get_preset(name), "cuda", seed=i, std=0.05)
+        eng = Engine(m, num_kv_blocks=256, block_size=16, max_model_len=512, use_graphs=False, max_prefill_tokens=96)
+        engines.append(eng)
+        be = EngineBackend(eng, ByteLevelTokenizer(m.cfg.vocab_size), stop_at_eos=False)
+        members.append(Member(core.default_personas()[i], be,
+                              params=GenParams(temperature=0.8, top_p=0.9, max_new_tokens=6, seed=i)))
+    vote = MajorityVote(members, decision_mode="logprob", device="cuda")
+    qs = ["Which? A. a B. b C. c D. d " + "x" * 40 * k for k in range(1, 4)]
+    vote.ask_many(qs)                                    # first use: lazy initialisation happens here
+    eng = engines[0]
+
+    def direct():
+        rids = [eng.submit(list(range(3, 140)), n=4, params=params(5, seed=1, temperature=0.7, top_p=0.9),
+                           decision_ids=[5, 6, 7]),
+                eng.submit(list(range(9, 60)), core.RequestKind.Score, score_ids=[1, 2, 3, 4, 5]),
+                eng.submit(list(range(20, 150)), core.RequestKind.Embed)]
+        eng.step()
+        rids.append(eng.submit(list(range(30, 100)), params=params(3, seed=2)))      # joins as riders go on
+        eng.run_until_done()
+        return [eng.pop_result(r) for r in rids]
+
+    direct()
+    torch.cuda.synchronize()
+    with AtenAudit() as audit:
+        res = vote.ask_many(qs)
+        outs = direct()
+        torch.cuda.synchronize()
+    assert all(r.answer in "ABCD" for r in res) and outs[2].embedding is not None and len(outs[1].scores) == 5
+    assert audit.kernels == {}, audit.kernels

@@ -117,28 +117,29 @@ def test_expert_parallel_four_ranks_uneven_token_count():
         assert np.allclose(got, want, atol=0.05)
 
 
-def test_expert_parallel_a2a_measured_capacity_path(monkeypatch):
-    """Above EP_FIXED_MAX_ROWS routed rows per rank the exchange buffers are sized from the
-    largest actual per-destination count (agreed on by all ranks) instead of the worst case;
-    the result must not change. The exchange itself is built from the permute / pack / index
-    kernels' outputs: no sort, histogram or host copy in parallel/ep.py."""
+def test_expert_parallel_a2a_chunked_exchange_never_reads_the_host(monkeypatch):
+    """A slice with more routed rows than one exchange carries is cut into chunks; every chunk's
+    exchange has the worst-case capacity per (source, destination) pair and the row counts
+    travel on the device next to the rows. The result must not change with the chunk size, and
+    nothing in parallel/ep.py may sort, count or read a device value on the host."""
     import inspect
 
     from llm_consensus_amd.parallel import ep
 
     src = inspect.getsource(ep.moe_all_to_all)
-    for banned in ("argsort", "bincount", "index_add_", ".cpu()"):
+    for banned in ("argsort", "bincount", "index_add_", ".cpu()", ".item()", "torch.cat", "tolist"):
         assert banned not in src, banned
     cfg = get_preset("tiny-mixtral")
     want, _ = _probe(TransformerModel.random_init(cfg, "cpu", seed=12, std=0.08), PROMPTS, TARGETS)
-    monkeypatch.setattr(ep, "EP_FIXED_MAX_ROWS", 2)
+    for chunk_rows in (4, 6, 1024):
+        monkeypatch.setattr(ep, "EP_CHUNK_ROWS", chunk_rows)
 
-    def rank(comm):
-        m = TransformerModel.random_init(cfg, "cpu", seed=12, std=0.08, comm=comm, ep_size=2, ep_mode="a2a")
-        return _probe(m, PROMPTS, TARGETS)
+        def rank(comm):
+            m = TransformerModel.random_init(cfg, "cpu", seed=12, std=0.08, comm=comm, ep_size=2, ep_mode="a2a")
+            return _probe(m, PROMPTS, TARGETS)
 
-    for got, _ in run_loopback(2, rank):
-        assert np.allclose(got, want, atol=0.05), np.abs(got - want).max()
+        for got, _ in run_loopback(2, rank):
+            assert np.allclose(got, want, atol=0.05), (chunk_rows, np.abs(got - want).max())
 
 
 def test_invalid_parallel_layouts_are_rejected():
@@ -282,18 +283,14 @@ def test_leader_follower_serving_loop():
     assert res[0][0][0] == res[0][1]
 
 
-def test_only_fixed_capacity_ep_steps_are_graph_capturable():
+def test_every_expert_parallel_step_is_graph_capturable():
     from llm_consensus_amd.models.config import get_preset
     from llm_consensus_amd.models.transformer import TransformerModel
-    from llm_consensus_amd.parallel.ep import EP_FIXED_MAX_ROWS
 
     cfg = get_preset("tiny-mixtral")
-    k = cfg.experts_per_tok
-    a2a = TransformerModel.random_init(cfg, torch.device("cpu"), seed=0, ep_size=2, ep_mode="a2a")
-    assert a2a.decode_capturable(2 * EP_FIXED_MAX_ROWS // k)
-    assert not a2a.decode_capturable(2 * EP_FIXED_MAX_ROWS // k + 2)
-    ar = TransformerModel.random_init(cfg, torch.device("cpu"), seed=0, ep_size=2, ep_mode="allreduce")
-    assert ar.decode_capturable(1 << 20)
+    for mode in ("a2a", "allreduce"):
+        m = TransformerModel.random_init(cfg, torch.device("cpu"), seed=0, ep_size=2, ep_mode=mode)
+        assert m.decode_capturable(1) and m.decode_capturable(1 << 20)
 
 
 
