@@ -6,6 +6,10 @@
 //                     Top-k / top-p never sort the vocabulary: the kept set is {z >= thr}
 //                     and thr is found by a 12-way threshold search (per-thread LDS
 //                     histograms), each sweep one coalesced 16-byte-per-lane pass over the row.
+//                     The top-p cut is DEFINED by that search: the largest threshold of the
+//                     grid refined kSearchPassesP times inside [max - 30, max] whose kept mass
+//                     still reaches top_p (at most 1.4e-3 below the exact sort-based cut; the
+//                     host oracle ops/reference.py::top_p_threshold implements the same rule).
 //   lc_logprob_gather log-softmax over the vocabulary, gathered at given target ids: the
 //                     constrained decision used for verdicts ("Good" vs "NeedsRefinement",
 //                     the two words the reference's parser accepts,

@@ -101,8 +101,7 @@ class _DecodeGraph:
         total = sum(n for _, n in fields)
         if dev.type == "cuda":
             # device block and pinned host mirror from the engine's runtime arenas
-            self.arena = eng.rt.small.tensor((total,), torch.int32)
-            self.arena.zero_()
+            self.arena = ops.zero_(eng.rt.small.tensor((total,), torch.int32))
             hnp = eng.rt.pinned.array((total,), np.int32)
             hnp[:] = 0
             self.host = None
@@ -586,7 +585,8 @@ class Engine:
             # LC_RCCL_CAPTURE=0 asks for eager steps: this is where a group lands whose
             # peer-to-peer collectives failed their first-contact check (parallel/p2p.py).
             use_graphs = capturable or (bool(getattr(model.comm, "capturable_thread_local", False))
-                                        and os.environ.get("LC_RCCL_CAPTURE", "1") == "1")
+                                        and os.environ.get("LC_RCCL_CAPTURE", "1") == "1"
+                                        and os.environ.get("CONSENSUS_PIECEWISE", "0") not in ("lists", "graphs"))
         elif use_graphs and not capturable and self.device.type == "cuda" and \
                 not getattr(model.comm, "capturable_thread_local", False):
             raise ValueError(f"{name}: use_graphs=True needs a group communicator whose collectives can be recorded "
@@ -626,8 +626,7 @@ class Engine:
         self._ahead = None          # (plan, token) of a step launched by end_step for the next begin_step
         rows_cap = max_batch_seqs              # no decode step (bucket padding included) has more rows
         if self.rt is not None:
-            self.last_tokens = self.rt.small.tensor((rows_cap,), torch.int32)
-            self.last_tokens.zero_()
+            self.last_tokens = ops.zero_(self.rt.small.tensor((rows_cap,), torch.int32))
         else:
             self.last_tokens = torch.zeros(rows_cap, dtype=torch.int32, device=self.device)
         self._dec_cache = None      # (request ids, rows with decision targets) of the newest decode batch

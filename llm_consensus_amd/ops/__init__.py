@@ -582,6 +582,18 @@ def logprob_merge(parts: torch.Tensor, C: int) -> torch.Tensor:
     return out
 
 
+def zero_(t: torch.Tensor) -> torch.Tensor:
+    """Fills a contiguous tensor whose size is a multiple of 4 bytes with zero bits (in place)."""
+    if not t.is_cuda:
+        return t.zero_()
+    nbytes = t.numel() * t.element_size()
+    if nbytes % 4 or not t.is_contiguous():
+        raise ValueError("zero_ needs a contiguous tensor of a multiple of 4 bytes")
+    if nbytes:
+        _hip().call("lc_fill_f32", t.data_ptr(), 0.0, nbytes // 4)
+    return t
+
+
 def accumulate_(y: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
     """y += x for fp32 tensors of one shape (in place)."""
     if not y.is_cuda:
@@ -722,7 +734,9 @@ def experts_on_sorted(x: torch.Tensor, row_index: Optional[torch.Tensor], offset
     h = _hip()
     off_ptr = offsets.data_ptr() + 4 * expert0          # the kernels index rows by absolute offsets
     act = torch.empty(rows_bound, dff, dtype=x.dtype, device=dev)
-    y = (torch.zeros if zero_unwritten else torch.empty)(rows_bound, d, dtype=x.dtype, device=dev)
+    y = torch.empty(rows_bound, d, dtype=x.dtype, device=dev)
+    if zero_unwritten:
+        zero_(y)
     # Decode steps (a few dozen routed rows in total): every expert's weights are streamed once
     # against one small panel. Prefill-sized batches use the tiled grouped kernels.
     gg = "lc_gemm_panel_grouped" if rows_bound <= MOE_PANEL_MAX_ROWS else "lc_gemm_grouped"

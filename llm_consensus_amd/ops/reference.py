@@ -159,10 +159,60 @@ def attn_decode(q: torch.Tensor, k_cache, vt_cache, block_tables, ctx_lens, Hq, 
 
 
 # ------------------------------------------------------------------ sampling
+TOP_P_SEARCH_RANGE = 30.0     # the threshold search starts this far below the row maximum (logit / T units)
+TOP_P_SEARCH_BINS = 12        # thresholds tried per refinement
+TOP_P_SEARCH_PASSES = 4       # refinements: resolution 30 / 12^4 = 1.4e-3
+
+
+def top_p_threshold(z: torch.Tensor, keep: torch.Tensor, p: float, floor: float = float("-inf")) -> float:
+    """The nucleus cut as sampling.hip finds it: the kept set is {z >= thr}, and thr is the
+    LARGEST threshold on a grid, refined TOP_P_SEARCH_PASSES times by a factor of
+    TOP_P_SEARCH_BINS inside [max - TOP_P_SEARCH_RANGE, max], whose kept mass still reaches
+    p * mass(keep). Against the exact top-p (sort, cumulative sum) this keeps, besides the exact
+    nucleus, at most the entries within 30 / 12^4 = 1.4e-3 of the exact cut; on the flat
+    distributions of a random-init model that is a few entries of ~1e-5 of the mass each. The
+    definition is what both the kernel and this oracle implement, so their draws agree token for
+    token (the arithmetic of the grid is done in fp32 here as there)."""
+    import numpy as np
+
+    f32 = np.float32
+    zz = z.to(torch.float32).numpy()
+    live = keep.numpy()
+    zmax = f32(zz[live].max()) if live.any() else f32(0.0)
+    mass = np.where(live, np.exp((zz - zmax).astype(np.float64)), 0.0)
+    target = p * float(mass.sum())
+    lo, hi = f32(max(f32(floor), zmax - f32(TOP_P_SEARCH_RANGE))), zmax
+    thr = f32(floor)
+    above, hi_is_max = 0.0, True
+    for _ in range(TOP_P_SEARCH_PASSES):
+        w = f32((hi - lo) * f32(1.0 / TOP_P_SEARCH_BINS))
+        inv_w = f32(1.0) / w if w > 0 else f32(0.0)
+        cand = live & (zz >= lo) & (np.ones_like(live) if hi_is_max else (zz < hi))
+        b = np.minimum(((zz - lo) * inv_w).astype(np.int64), TOP_P_SEARCH_BINS - 1)
+        bins = np.bincount(b[cand], weights=mass[cand], minlength=TOP_P_SEARCH_BINS)
+        cum, best, above_best = above, -1, above
+        for j in range(TOP_P_SEARCH_BINS - 1, -1, -1):
+            before = cum
+            cum += float(bins[j])
+            if cum >= target:
+                best, above_best = j, before
+                break
+        if best < 0:
+            break
+        nlo = f32(lo + w * f32(best))
+        if best < TOP_P_SEARCH_BINS - 1:
+            hi = f32(lo + w * f32(best + 1))
+            hi_is_max = False
+            above = above_best
+        lo = nlo
+        thr = lo
+    return float(thr)
+
+
 def sample(logits: torch.Tensor, temperature, top_p, top_k, seeds, steps, row_index=None):
-    """Same definition as sampling.hip: scale by 1/T, keep the k largest, then the smallest
-    prefix (by descending prob) whose mass reaches top_p * mass(top-k set), draw by inverse
-    CDF in *index* order with u = rng_uniform(seed, step)."""
+    """Same definition as sampling.hip: scale by 1/T, keep the k largest, then the nucleus
+    {z >= thr} with thr from ``top_p_threshold`` (relative to the mass that survived top-k), draw
+    by inverse CDF in *index* order with u = rng_uniform(seed, step)."""
     R = len(temperature)
     toks = torch.zeros(R, dtype=torch.int32)
     lps = torch.zeros(R, dtype=torch.float32)
@@ -174,22 +224,21 @@ def sample(logits: torch.Tensor, temperature, top_p, top_k, seeds, steps, row_in
             t = int(torch.argmax(row))
             toks[r], lps[r] = t, float(lp[t])
             continue
+        z32 = (logits[int(row_index[r]) if row_index is not None else r].float().cpu()
+               * torch.tensor(1.0 / T, dtype=torch.float32))
         z = row / T
         w = torch.exp(z - z.max())
         order = torch.argsort(w, descending=True, stable=True)
         keep = torch.ones_like(w, dtype=torch.bool)
         k = int(top_k[r]) if top_k is not None else 0
+        floor = float("-inf")
         if 0 < k < w.numel():
             kth = w[order[k - 1]]
             keep &= w >= kth
+            floor = float(z32[order[k - 1]])
         p = float(top_p[r]) if top_p is not None else 1.0
         if p < 1.0:
-            ws = torch.where(keep, w, torch.zeros_like(w))[order]
-            csum = torch.cumsum(ws, 0)
-            target = p * float(ws.sum())
-            n_keep = int(torch.searchsorted(csum, torch.tensor(target, dtype=csum.dtype)).item()) + 1
-            thr = ws[min(n_keep, ws.numel()) - 1]
-            keep &= w >= thr
+            keep &= z32 >= top_p_threshold(z32, keep, p, floor)
         wk = torch.where(keep, w, torch.zeros_like(w))
         u = rng_uniform(int(seeds[r]), int(steps[r]) if steps is not None else 0)
         csum = torch.cumsum(wk, 0)

@@ -439,34 +439,38 @@ def test_sampler_matches_reference_definition(V):
 
 @pytest.mark.parametrize("top_p", [0.5, 0.9, 0.95, 0.99])
 def test_top_p_threshold_resolution_on_flat_distributions(top_p):
-    """The nucleus cut is found by a threshold search with a resolution of about 1.4e-3 in units
-    of logit / temperature (four 12-way sweeps over a range of 30). On flat distributions (what
-    random-init models produce: tens of thousands of near-tied entries) entries that close to
-    the exact cut may be kept or dropped differently from the exact top-p of the host oracle.
-    Pinned here: over many seeds the kernel's token equals the oracle's for almost every row, and
-    where it differs BOTH tokens lie within that resolution of the exact cut (each such entry
-    carries ~1e-5 of the mass). No reference fixture covers this: parity is otherwise unpinned."""
+    """The nucleus cut is DEFINED as the largest threshold of a grid refined four times by a
+    factor of 12 inside [max - 30, max] (resolution 1.4e-3 in logit / T units) whose kept mass
+    still reaches top_p (ops.reference.top_p_threshold states it; the kernel implements it). On
+    flat distributions (what random-init models produce: tens of thousands of near-tied entries)
+    an exact sort-based cut would differ from it by the handful of entries within that
+    resolution of the cut, enough to move the inverse-CDF draw to a neighbouring token in about
+    half the rows; against the oracle of the same definition the kernel's tokens agree. Checked
+    as well: the cut sits at most one resolution step below the exact top-p cut (the nucleus is a
+    superset of the exact one by a few entries of ~1e-5 of the mass). No reference fixture
+    covers sampling: parity with other samplers is unpinned."""
     V, R, T = 32000, 192, 0.8
     logits = rand(R, V, scale=0.35, seed=int(top_p * 100))       # flat: the nucleus holds most of the vocabulary
     temp = torch.full((R,), T)
     tp = torch.full((R,), top_p)
     seeds = torch.arange(R, dtype=torch.int64) * 104729 + 11
     steps = torch.arange(R, dtype=torch.int32) % 7
-    tok, _ = ops.sample(logits.to(DEV), temp.to(DEV), tp.to(DEV), None, seeds.to(DEV), steps.to(DEV))
-    want, _ = ref.sample(logits, temp, tp, torch.zeros(R, dtype=torch.int32), seeds, steps)
+    tok, lp = ops.sample(logits.to(DEV), temp.to(DEV), tp.to(DEV), None, seeds.to(DEV), steps.to(DEV))
+    want, wlp = ref.sample(logits, temp, tp, torch.zeros(R, dtype=torch.int32), seeds, steps)
     tok = tok.cpu()
     diff = torch.nonzero(tok != want).flatten().tolist()
-    # an entry kept or dropped at the cut moves the kept mass by ~1e-5, which can carry the draw
-    # over the boundary to the neighbouring kept entry: still a draw from (almost) the same nucleus
-    print(f"top_p={top_p}: {len(diff)} of {R} rows differ from the exact-threshold oracle")
-    assert len(diff) <= R // 4, (len(diff), diff[:8])
+    print(f"top_p={top_p}: {len(diff)} of {R} rows differ from the oracle")
+    assert len(diff) <= R // 16, (len(diff), diff[:8])       # fp32 rounding at a grid point or a CDF boundary
+    same = tok == want
+    assert torch.allclose(lp.cpu()[same], wlp[same], atol=2e-3)
     scaled = logits / T
-    for r in diff:
+    for r in list(range(0, R, 16)) + diff:
         srt, _ = torch.sort(scaled[r], descending=True)
-        cdf = torch.cumsum(torch.softmax(srt, -1), -1)
-        cut = float(srt[int(torch.searchsorted(cdf, torch.tensor(top_p)))])
-        for t in (int(tok[r]), int(want[r])):
-            assert float(scaled[r, t]) >= cut - 5e-3, (r, t, float(scaled[r, t]), cut)
+        cdf = torch.cumsum(torch.softmax(srt.double(), -1), -1)
+        cut = float(srt[int(torch.searchsorted(cdf, torch.tensor(top_p, dtype=torch.float64)))])
+        thr = ref.top_p_threshold(scaled[r], torch.ones(V, dtype=torch.bool), top_p)
+        assert cut - 3e-3 <= thr <= cut + 1e-6, (r, thr, cut)
+        assert float(scaled[r, int(tok[r])]) >= thr - 1e-5, (r, int(tok[r]))
 
 
 def test_sampler_never_returns_an_out_of_range_token_for_poisoned_rows():
