@@ -433,76 +433,106 @@ class JudgeLogprob:
         """What every judge prompt of a question starts with (see ``warm_judges``)."""
         return f"Question: {question}\nProposed answer:"
 
-    def ask_many(self, questions: Sequence[str]) -> List[ConsensusResult]:
-        t0 = time.perf_counter()
+    # One question's way through the strategy, in the three pieces every driver uses: the batch
+    # driver below (micro-batch pipeline) and the continuous one (PhasedPool).
+    def _begin(self, question: str) -> dict:
+        """Queues the proposals (and, with ``warm_judges``, the judges' look at the question)."""
+        st = {"prop": [m.submit_propose(question, self.params) for m in self.proposers], "cands": [], "score": [],
+              "warm": []}
+        if self.warm_judges:
+            st["warm"] = [j.backend.submit_score(self.judge_prompt_head(question), self.JUDGE_TARGETS)
+                          for j in self.judges]
+        return st
+
+    @staticmethod
+    def _first_handles(st: dict) -> list:
+        return st["prop"]
+
+    def _second(self, question: str, st: dict) -> None:
+        """Proposals are in: every judge scores every candidate."""
+        row = []
+        for i, h in enumerate(st["prop"]):
+            try:
+                row.append(Member.finish_text(h))
+            except BackendError as e:
+                log.error("%s failed: %s", self.proposers[i].name, e)
+                row.append("")
+        st["cands"] = row
+        st["score"] = [[j.backend.submit_score(self.judge_prompt(question, c), self.JUDGE_TARGETS)
+                        for j in self.judges] for c in row]
+
+    @staticmethod
+    def _second_handles(st: dict) -> list:
+        return [h for row in st["score"] for h in row]
+
+    def _finish(self, questions: Sequence[str], states: Sequence[dict], t0s: Sequence[float]) -> List[ConsensusResult]:
+        """Scores of finished questions -> results (one reducer launch for all of them)."""
         R = len(questions)
-        prop: List[list] = [[] for _ in range(R)]
-        cands: List[List[str]] = [[] for _ in range(R)]
-        score_h: List[list] = [[] for _ in range(R)]
-        warm_h: List[list] = [[] for _ in range(R)]
-
-        def propose(rng) -> None:
-            for r in rng:
-                prop[r] = [m.submit_propose(questions[r], self.params) for m in self.proposers]
-                if self.warm_judges:
-                    warm_h[r] = [j.backend.submit_score(self.judge_prompt_head(questions[r]), self.JUDGE_TARGETS)
-                                 for j in self.judges]
-
-        def judge(rng) -> None:
-            for r in rng:
-                row = []
-                for i, h in enumerate(prop[r]):
-                    try:
-                        row.append(Member.finish_text(h))
-                    except BackendError as e:
-                        log.error("%s failed: %s", self.proposers[i].name, e)
-                        row.append("")
-                cands[r] = row
-                score_h[r] = [[j.backend.submit_score(self.judge_prompt(questions[r], c), self.JUDGE_TARGETS)
-                               for j in self.judges] for c in row]
-
-        first = list(self.proposers) + (list(self.judges) if self.warm_judges else [])
-        _two_stage_pipeline(R, self.micro_batches, propose, first, judge, self.judges,
-                            min_part=self.min_micro_batch)
-        for row in warm_h:                       # a failed warm-up costs nothing but the cache hit
-            for h in row:
+        for st in states:                        # a failed warm-up costs nothing but the cache hit
+            for h in st["warm"]:
                 try:
                     h.result()
                 except BackendError:
                     pass
         C, J = len(self.proposers), len(self.judges)
         scores = np.full((R, C, J), -1e30, dtype=np.float32)
-        done_at = [t0] * R
-        for r in range(R):
+        done_at = list(t0s)
+        for r, st in enumerate(states):
             for c in range(C):
-                if not cands[r][c]:
+                if not st["cands"][c]:
                     continue
                 for j in range(J):
+                    h = st["score"][c][j]
                     try:
-                        lp = score_h[r][c][j].result()
+                        lp = h.result()
                         scores[r, c, j] = float(lp[0]) - float(lp[1])
                     except BackendError as e:
                         log.error("%s failed to score: %s", self.judges[j].name, e)
                         scores[r, c, j] = 0.0
-                    done_at[r] = max(done_at[r], score_h[r][c][j].finished_at or t0)
+                    done_at[r] = max(done_at[r], h.finished_at or t0s[r])
         with span("reduce", "strategy"):
             red = reducers.judge_reduce_batch(scores, device=self.device)
         out = []
-        for r, q in enumerate(questions):
+        for r, (q, st) in enumerate(zip(questions, states)):
             w = int(red.winner[r])
             out.append(ConsensusResult(
-                question=q, answer=cands[r][w] if w >= 0 else "", strategy=self.name, rounds=1,
+                question=q, answer=st["cands"][w] if w >= 0 else "", strategy=self.name, rounds=1,
                 member_calls=C + C * J, unanimous=bool(red.unanimous[r]),
                 proposer=self.proposers[w].name if w >= 0 else None,
-                latency_s=(done_at[r] - t0) if done_at[r] > t0 else time.perf_counter() - t0,
+                latency_s=(done_at[r] - t0s[r]) if done_at[r] > t0s[r] else time.perf_counter() - t0s[r],
                 votes=[{"candidate": self.proposers[c].name, "scores": scores[r, c].tolist()} for c in range(C)],
                 extra={"winner_score": float(red.score[r])},
-                usage=add_usage({}, list(prop[r]) + [h for row in score_h[r] for h in row] + list(warm_h[r])),
+                usage=add_usage({}, list(st["prop"]) + self._second_handles(st) + list(st["warm"])),
             ))
         return out
 
+    def ask_many(self, questions: Sequence[str]) -> List[ConsensusResult]:
+        t0 = time.perf_counter()
+        R = len(questions)
+        states: List[Optional[dict]] = [None] * R
+
+        def propose(rng) -> None:
+            for r in rng:
+                states[r] = self._begin(questions[r])
+
+        def judge(rng) -> None:
+            for r in rng:
+                self._second(questions[r], states[r])
+
+        first = list(self.proposers) + (list(self.judges) if self.warm_judges else [])
+        _two_stage_pipeline(R, self.micro_batches, propose, first, judge, self.judges,
+                            min_part=self.min_micro_batch)
+        return self._finish(questions, states, [t0] * R)
+
     def ask(self, question: str) -> ConsensusResult:
         return self.ask_many([question])[0]
+
+    @property
+    def members(self) -> List[Member]:
+        return list(self.proposers) + list(self.judges)
+
+    def pool(self) -> "PhasedPool":
+        return PhasedPool(self)
 
 
 class EmbeddingMedoid:
@@ -521,54 +551,127 @@ class EmbeddingMedoid:
         self.micro_batches = micro_batches
         self.min_micro_batch = min_micro_batch
 
-    def ask_many(self, questions: Sequence[str]) -> List[ConsensusResult]:
-        t0 = time.perf_counter()
-        R = len(questions)
-        prop: List[list] = [[] for _ in range(R)]
-        cands: List[List[str]] = [[] for _ in range(R)]
-        owners: List[List[str]] = [[] for _ in range(R)]
-        emb_h: List[list] = [[] for _ in range(R)]
+    def _begin(self, question: str) -> dict:
+        row = []
+        for m in self.proposers:
+            p = self.params or m.params
+            if self.samples > 1:
+                p = GenParams(**{**p.__dict__, "n": self.samples})
+            row.append(m.submit_propose(question, p))
+        return {"prop": row, "cands": [], "owners": [], "emb": []}
 
-        def propose(rng) -> None:
-            for r in rng:
-                row = []
-                for m in self.proposers:
-                    p = self.params or m.params
-                    if self.samples > 1:
-                        p = GenParams(**{**p.__dict__, "n": self.samples})
-                    row.append(m.submit_propose(questions[r], p))
-                prop[r] = row
+    @staticmethod
+    def _first_handles(st: dict) -> list:
+        return st["prop"]
 
-        def embed(rng) -> None:
-            for r in rng:
-                for i, h in enumerate(prop[r]):
-                    try:
-                        for t in h.result().texts:
-                            cands[r].append(t)
-                            owners[r].append(self.proposers[i].name)
-                    except BackendError as e:
-                        log.error("%s failed: %s", self.proposers[i].name, e)
-                emb_h[r] = [self.embedder.backend.submit_embed(c) for c in cands[r]]
+    def _second(self, question: str, st: dict) -> None:
+        """Proposals are in: the embedder embeds every candidate."""
+        for i, h in enumerate(st["prop"]):
+            try:
+                for t in h.result().texts:
+                    st["cands"].append(t)
+                    st["owners"].append(self.proposers[i].name)
+            except BackendError as e:
+                log.error("%s failed: %s", self.proposers[i].name, e)
+        st["emb"] = [self.embedder.backend.submit_embed(c) for c in st["cands"]]
 
-        _two_stage_pipeline(R, self.micro_batches, propose, self.proposers, embed, [self.embedder],
-                            names=("generate", "embed"), min_part=self.min_micro_batch)
+    @staticmethod
+    def _second_handles(st: dict) -> list:
+        return st["emb"]
+
+    def _finish(self, questions: Sequence[str], states: Sequence[dict], t0s: Sequence[float]) -> List[ConsensusResult]:
         out = []
-        for r, q in enumerate(questions):
-            if not cands[r]:
+        for q, st, t0 in zip(questions, states, t0s):
+            if not st["cands"]:
                 out.append(ConsensusResult(question=q, answer="", strategy=self.name, extra={"error": "no candidates"}))
                 continue
-            E = np.stack([np.asarray(h.result(), dtype=np.float32) for h in emb_h[r]])
+            E = np.stack([np.asarray(h.result(), dtype=np.float32) for h in st["emb"]])
             red = reducers.cosine_medoid(E, device=self.device)
-            done = max((h.finished_at or t0) for h in emb_h[r])
+            done = max((h.finished_at or t0) for h in st["emb"])
             out.append(ConsensusResult(
-                question=q, answer=cands[r][red.index], strategy=self.name, rounds=1,
-                member_calls=len(self.proposers) + len(cands[r]), proposer=owners[r][red.index],
+                question=q, answer=st["cands"][red.index], strategy=self.name, rounds=1,
+                member_calls=len(self.proposers) + len(st["cands"]), proposer=st["owners"][red.index],
                 latency_s=(done - t0) if done > t0 else time.perf_counter() - t0, agreement=float(red.mean_pairwise),
-                votes=[{"candidate": owners[r][i], "text": c} for i, c in enumerate(cands[r])],
+                votes=[{"candidate": st["owners"][i], "text": c} for i, c in enumerate(st["cands"])],
                 extra={"medoid_score": float(red.score)},
-                usage=add_usage({}, list(prop[r]) + list(emb_h[r])),
+                usage=add_usage({}, list(st["prop"]) + list(st["emb"])),
             ))
         return out
 
+    def ask_many(self, questions: Sequence[str]) -> List[ConsensusResult]:
+        t0 = time.perf_counter()
+        R = len(questions)
+        states: List[Optional[dict]] = [None] * R
+
+        def propose(rng) -> None:
+            for r in rng:
+                states[r] = self._begin(questions[r])
+
+        def embed(rng) -> None:
+            for r in rng:
+                self._second(questions[r], states[r])
+
+        _two_stage_pipeline(R, self.micro_batches, propose, self.proposers, embed, [self.embedder],
+                            names=("generate", "embed"), min_part=self.min_micro_batch)
+        return self._finish(questions, states, [t0] * R)
+
     def ask(self, question: str) -> ConsensusResult:
         return self.ask_many([question])[0]
+
+    @property
+    def members(self) -> List[Member]:
+        return list(self.proposers) + [self.embedder]
+
+    def pool(self) -> "PhasedPool":
+        return PhasedPool(self)
+
+
+class PhasedPool:
+    """The two-phase strategies (JudgeLogprob, EmbeddingMedoid) without batch boundaries:
+    questions are admitted at any time; each one queues its proposals, moves on to its second
+    phase (judge scores / embeddings) the moment ITS proposals are in, and is answered when its
+    own second phase is done, while the engines are advanced one step at a time in between. The
+    reference moves a question from proposal to evaluation the same way, as the replies arrive
+    (/root/reference/src/main.rs:242-257), for one question; here for as many as are in flight.
+    Same interface as VotePool / protocol.SessionPool."""
+
+    def __init__(self, strategy) -> None:
+        self.s = strategy
+        self.backends = distinct_backends(strategy.members)
+        self.stepper = BackendStepper(self.backends)
+        self.live: dict = {}          # ticket -> [question, t0, stage, state]
+        self._next = 0
+
+    @property
+    def active(self) -> int:
+        return len(self.live)
+
+    def submit(self, question: str) -> int:
+        t = self._next
+        self._next += 1
+        self.live[t] = [question, time.perf_counter(), 1, self.s._begin(question)]
+        return t
+
+    def pump(self) -> List[tuple]:
+        done = []
+        for t, e in self.live.items():
+            q, _, stage, st = e
+            if stage == 1 and all(h.done for h in self.s._first_handles(st)):
+                self.s._second(q, st)
+                e[2] = stage = 2
+            if stage == 2 and all(h.done for h in self.s._second_handles(st)):
+                done.append(t)
+        finished: List[tuple] = []
+        if done:
+            rows = [self.live.pop(t) for t in done]
+            res = self.s._finish([r[0] for r in rows], [r[3] for r in rows], [r[1] for r in rows])
+            finished = list(zip(done, res))
+        if self.live and not self.stepper.step() and not finished:
+            time.sleep(20e-6)
+        return finished
+
+    def drain(self) -> List[tuple]:
+        out = []
+        while self.live:
+            out += self.pump()
+        return out

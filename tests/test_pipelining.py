@@ -172,3 +172,24 @@ def test_self_consistency_pool_matches_batch():
         assert got[i].answer == batch[i].answer
         assert [v["class"] for v in got[i].votes] == [v["class"] for v in batch[i].votes]
         assert got[i].extra["chains"] == batch[i].extra["chains"]
+
+
+@pytest.mark.parametrize("strategy", ["judge_logprob", "embedding_medoid"])
+def test_two_phase_strategies_without_batch_boundaries(strategy):
+    """PhasedPool: a question moves to its second phase the moment ITS proposals are in and is
+    answered when its own second phase is done; questions admitted later join the engines'
+    running batches. Answers equal those of the batch driver."""
+    ens = build_ensemble(two_phase_config(strategy, 1), CPU)
+    want = {r.question: (r.answer, r.proposer) for r in ens.ask_many(QUESTIONS)}
+    pool = ens.strategy.pool()
+    tickets = {pool.submit(q): q for q in QUESTIONS[:2]}
+    got, pumps, late = {}, 0, list(QUESTIONS[2:])
+    while pool.active or late:
+        pumps += 1
+        if late and pumps % 3 == 0:                       # arrivals while others are in flight
+            q = late.pop(0)
+            tickets[pool.submit(q)] = q
+        for t, r in pool.pump():
+            got[tickets[t]] = (r.answer, r.proposer)
+    assert got == want
+    assert pool.drain() == []
