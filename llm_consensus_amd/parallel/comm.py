@@ -84,6 +84,11 @@ class Comm:
     def all_gather_object(self, obj) -> list:
         return [obj]
 
+    def all_gather_bytes(self, data: bytes) -> List[bytes]:
+        """Every rank's byte string, in rank order (a serialised record per rank; the caller
+        chooses the encoding). The default carries them as host objects."""
+        return [bytes(x) for x in self.all_gather_object(bytes(data))]
+
     def subgroup(self, ranks: Sequence[int]) -> "Comm":
         """Communicator over ``ranks`` (ranks of THIS communicator, ascending). Collective:
         every rank of this communicator must call it with the same arguments in the same
@@ -204,6 +209,23 @@ class TorchDistComm(Comm):
         out: List[object] = [None] * self.world
         self.dist.all_gather_object(out, obj, group=self.group)
         return out
+
+    def all_gather_bytes(self, data: bytes) -> List[bytes]:
+        """Two tensor collectives on the group's own transport (device memory under RCCL): the
+        lengths, then the byte strings padded to the longest. Nothing is pickled."""
+        dev = "cpu" if self.staged else self.device
+        n = torch.tensor([len(data)], dtype=torch.int64, device=dev)
+        sizes = torch.empty(self.world, dtype=torch.int64, device=dev)
+        self.dist.all_gather_into_tensor(sizes, n, group=self.group)
+        sizes = sizes.cpu().tolist()
+        cap = max(1, max(sizes))
+        buf = torch.zeros(cap, dtype=torch.uint8)
+        if data:
+            buf[: len(data)] = torch.frombuffer(bytearray(data), dtype=torch.uint8)
+        out = torch.empty(self.world * cap, dtype=torch.uint8, device=dev)
+        self.dist.all_gather_into_tensor(out, buf.to(dev), group=self.group)
+        out = out.cpu()
+        return [bytes(out[r * cap: r * cap + sizes[r]].numpy().tobytes()) for r in range(self.world)]
 
     def subgroup(self, ranks: Sequence[int]) -> Optional["Comm"]:
         ranks = list(ranks)

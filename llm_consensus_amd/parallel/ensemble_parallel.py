@@ -23,6 +23,7 @@ ranks stay in step without exchanging decisions.
 """
 from __future__ import annotations
 
+import time
 from dataclasses import dataclass, field
 from typing import Any, Dict, List, Optional, Sequence
 
@@ -40,23 +41,37 @@ log = get_logger("consensus.parallel")
 
 class ShardedBackend(Backend):
     """Replica-wide facade of one model. ``local`` is the engine backend on ranks that host
-    the model (None elsewhere); ``owner`` is the replica rank that publishes results."""
+    the model (None elsewhere); ``owner`` is the replica rank that publishes results.
+
+    Results cross ranks as numbers wherever they are numbers: log-prob scores and embeddings as
+    one float32 table, generated answers as one int32 table of token ids (plus one float32 table
+    of their log-probs), from which every rank re-creates the text with its own copy of the
+    model's tokenizer. Only the message of a failed call travels as a host object. With
+    ``tokenizer`` None (backends without token ids: scripted fakes) answers travel as objects.
+
+    Two ways of publishing: ``sync()`` after a whole phase (the wave drivers), and
+    ``take_finished`` / ``complete`` request by request for the lock-step continuous driver
+    (LockstepDriver), which carries them in its per-round exchange."""
 
     def __init__(self, name: str, local: Optional[Backend], owner: int, comm: Comm, embed_dim: int = 0,
-                 device: Optional[torch.device] = None) -> None:
+                 device: Optional[torch.device] = None, tokenizer=None) -> None:
         self.name, self.local, self.owner, self.comm = name, local, owner, comm
         self.embed_dim = embed_dim           # width of an embedding row (0: embeddings travel as objects)
         self.device = device or torch.device("cpu")
-        self._pending: List[tuple] = []      # (handle, inner handle | None, numeric width | 0)
+        self.tok = tokenizer
+        self._pending: List[dict] = []       # submission order; every rank of the replica holds the same list
+        self._seq = 0
+        self._side = None                    # side stream of the publishing broadcasts (GPU)
 
-    def _submit(self, method: str, *args, width: int = 0) -> Handle:
+    def _submit(self, method: str, *args, width: int = 0, gen: Optional[GenParams] = None) -> Handle:
         h = Handle()
         inner = getattr(self.local, method)(*args) if self.local is not None else None
-        self._pending.append((h, inner, width))
+        self._pending.append({"seq": self._seq, "h": h, "inner": inner, "width": width, "gen": gen, "sent": False})
+        self._seq += 1
         return h
 
     def submit_generate(self, prompt: str, params: GenParams, on_text=None) -> Handle:
-        return self._submit("submit_generate", prompt, params)     # results arrive whole, after the exchange
+        return self._submit("submit_generate", prompt, params, gen=params)   # results arrive whole, after the exchange
 
     def submit_score(self, prompt: str, targets: Sequence[str]) -> Handle:
         return self._submit("submit_score", prompt, list(targets), width=len(targets))
@@ -64,65 +79,210 @@ class ShardedBackend(Backend):
     def submit_embed(self, text: str) -> Handle:
         return self._submit("submit_embed", text, width=self.embed_dim)
 
+    def token_ids_of(self, text: str):
+        return list(self.tok.encode(text, add_bos=False)) if self.tok is not None else None
+
     def run_local(self) -> None:
         if self.local is not None and self._pending:
             self.local.run()
 
+    # ------------------------------------------------------------------ wire forms
+    def _text_of(self, toks: Sequence[int]) -> str:
+        eos = self.tok.eos_id
+        if eos is not None and len(toks) and toks[-1] == eos:
+            toks = toks[:-1]
+        return self.tok.decode(list(toks))
+
+    def _gen_tables(self, entries: List[dict], results: List[Optional[tuple]], mine: bool):
+        """Int32 [rows, 4 + Tmax] and float32 [rows, 1 + Cmax] for the generation calls in
+        ``entries`` (one row per chain; every rank knows the shapes from the calls' parameters).
+        Row: status, length, prompt tokens, cached tokens, token ids | cum log-prob, decision log-probs."""
+        chains = [max(1, e["gen"].n) for e in entries]
+        tmax = max(1, max(e["gen"].max_new_tokens for e in entries))
+        cmax = max((len(e["gen"].decision_targets or []) for e in entries), default=0)
+        it = torch.zeros(sum(chains), 4 + tmax, dtype=torch.int32)
+        ft = torch.zeros(sum(chains), 1 + cmax, dtype=torch.float32)
+        if mine:
+            row = 0
+            for e, res, n in zip(entries, results, chains):
+                status, value, _ = res
+                ok = status == "ok" and bool(getattr(value, "token_ids", None)) and len(value.token_ids) <= n
+                for k in range(n):
+                    if ok and k < len(value.token_ids):
+                        ids = value.token_ids[k][:tmax]
+                        it[row, 0], it[row, 1] = 1, len(ids)
+                        it[row, 2], it[row, 3] = value.prompt_tokens, value.cached_tokens
+                        it[row, 4:4 + len(ids)] = torch.as_tensor(ids, dtype=torch.int32)
+                        ft[row, 0] = value.cum_logprobs[k] if k < len(value.cum_logprobs) else 0.0
+                        if value.decision_logprobs:
+                            d = value.decision_logprobs[k]
+                            ft[row, 1:1 + len(d)] = torch.as_tensor(d, dtype=torch.float32)
+                    row += 1
+        return it, ft, chains
+
+    def _gen_results(self, entries: List[dict], it: torch.Tensor, ft: torch.Tensor, chains: List[int]):
+        """The inverse of _gen_tables on any rank: (status, GenResult | None, usage) per entry."""
+        from ..consensus.backend import GenResult
+
+        out, row = [], 0
+        for e, n in zip(entries, chains):
+            rows = range(row, row + n)
+            row += n
+            live = [r for r in rows if int(it[r, 0]) == 1]
+            if not live:
+                out.append(None)                       # failed (or not expressible): the object path carries it
+                continue
+            ids = [it[r, 4:4 + int(it[r, 1])].tolist() for r in live]
+            C = len(e["gen"].decision_targets or [])
+            res = GenResult(texts=[self._text_of(t) for t in ids], token_ids=ids,
+                            cum_logprobs=[float(ft[r, 0]) for r in live],
+                            decision_logprobs=[ft[r, 1:1 + C].tolist() for r in live] if C else None,
+                            prompt_tokens=int(it[live[0], 2]), cached_tokens=int(it[live[0], 3]))
+            out.append(("ok", res, (res.prompt_tokens, sum(len(t) for t in ids), res.cached_tokens)))
+        return out
+
+    def _broadcast_tables(self, tables: List[torch.Tensor]) -> List[torch.Tensor]:
+        """Owner -> replica, on the communicator's own transport. On a GPU the copies and the
+        collectives are queued on a side stream (never behind an engine's step) and the host
+        waits for that stream's event only."""
+        if self.device.type != "cuda":
+            return [self.comm.broadcast(t, self.owner) for t in tables]
+        if self._side is None:
+            self._side = torch.cuda.Stream(self.device)
+        with torch.cuda.stream(self._side):
+            devs = [self.comm.broadcast(t.to(self.device, non_blocking=True), self.owner) for t in tables]
+            hosts = [d.to("cpu", non_blocking=True) for d in devs]
+            done = torch.cuda.Event()
+            done.record(self._side)
+        done.synchronize()
+        return hosts
+
     def sync(self) -> None:
-        """Publishes the results of the queued calls to every rank of the replica. Log-prob
-        scores and embeddings are rows of numbers whose widths every rank knows, so they travel
-        as ONE float32 tensor broadcast on the communicator's own transport (device memory under
-        RCCL): columns [0, width) hold the row, the next three the token usage, the last one a
-        status flag. Generated text, and the message of a failed call, go through one host-object
-        broadcast; a phase that only scored or embedded sends no pickled payload at all."""
+        """Publishes the results of the queued calls to every rank of the replica (see the class
+        comment for the wire forms). A phase without failures sends no pickled payload at all."""
         pend, self._pending = self._pending, []
         if not pend:
             return
         mine = self.comm.rank == self.owner
-        numeric = [i for i, (_, _, w) in enumerate(pend) if w > 0]
-        objects = [i for i, (_, _, w) in enumerate(pend) if w <= 0]
+        numeric = [i for i, e in enumerate(pend) if e["width"] > 0]
+        gens = [i for i, e in enumerate(pend) if e["gen"] is not None and self.tok is not None]
         results: List[Optional[tuple]] = [None] * len(pend)
         if mine:
-            for i, (_, inner, _) in enumerate(pend):
+            for i, e in enumerate(pend):
                 try:
-                    results[i] = ("ok", inner.result(), inner.usage)
-                except BackendError as e:
-                    results[i] = ("err", str(e), None)
+                    results[i] = ("ok", e["inner"].result(), e["inner"].usage)
+                except BackendError as err:
+                    results[i] = ("err", str(err), None)
         if self.comm.world > 1:
             with span(f"publish:{self.name}", "parallel", requests=len(pend)):
+                tables: List[torch.Tensor] = []
+                wmax = 0
                 if numeric:
-                    wmax = max(pend[i][2] for i in numeric)
+                    wmax = max(pend[i]["width"] for i in numeric)
                     table = torch.zeros(len(numeric), wmax + 4, dtype=torch.float32)
                     if mine:
                         for row, i in enumerate(numeric):
                             status, value, usage = results[i]
                             if status == "ok":
-                                table[row, :pend[i][2]] = torch.as_tensor(value, dtype=torch.float32).reshape(-1)
+                                table[row, :pend[i]["width"]] = torch.as_tensor(value, dtype=torch.float32).reshape(-1)
                                 table[row, wmax:wmax + 3] = torch.tensor([float(u) for u in (usage or (0, 0, 0))])
                                 table[row, wmax + 3] = 1.0
-                    table = self.comm.broadcast(table.to(self.device), self.owner).cpu()
-                    failed = [i for row, i in enumerate(numeric) if table[row, wmax + 3] == 0]
+                    tables.append(table)
+                chains: List[int] = []
+                if gens:
+                    it, ft, chains = self._gen_tables([pend[i] for i in gens], [results[i] for i in gens], mine)
+                    tables += [it, ft]
+                if tables:
+                    tables = self._broadcast_tables(tables)
+                settled = set()
+                if numeric:
+                    table = tables[0]
                     for row, i in enumerate(numeric):
                         if table[row, wmax + 3] != 0:
                             usage = tuple(int(u) for u in table[row, wmax:wmax + 3].tolist())
-                            results[i] = ("ok", table[row, :pend[i][2]].numpy().copy(), usage)
-                else:
-                    failed = []
-                rest = objects + failed
+                            results[i] = ("ok", table[row, :pend[i]["width"]].numpy().copy(), usage)
+                            settled.add(i)
+                if gens:
+                    got = self._gen_results([pend[i] for i in gens], tables[-2], tables[-1], chains)
+                    for i, r in zip(gens, got):
+                        if r is not None:
+                            results[i] = r
+                            settled.add(i)
+                rest = [i for i in range(len(pend)) if i not in settled]
                 if rest:
                     payload = self.comm.broadcast_object([results[i] for i in rest] if mine else None, self.owner)
                     for i, r in zip(rest, payload):
                         results[i] = r
-        for (h, _, _), (status, value, usage) in zip(pend, results):  # type: ignore[misc]
-            h.usage = usage
-            if status == "ok":
-                h.set_result(value)
-            else:
-                h.set_error(BackendError(value))
+        for e, (status, value, usage) in zip(pend, results):  # type: ignore[misc]
+            self._complete(e, status, value, usage)
+
+    @staticmethod
+    def _complete(e: dict, status: str, value, usage) -> None:
+        h = e["h"]
+        h.usage = tuple(usage) if usage else None
+        if status == "ok":
+            h.set_result(value)
+        else:
+            h.set_error(BackendError(value))
 
     def run(self) -> None:
         self.run_local()
         self.sync()
+
+    # ------------------------------------------------------------------ request-by-request publishing
+    def take_finished(self) -> List[dict]:
+        """Owner rank: wire records of the calls whose local handle has completed since the last
+        call (plain numbers, lists and strings; see ``complete``)."""
+        out = []
+        for e in self._pending:
+            if e["sent"] or e["inner"] is None or not e["inner"].done:
+                continue
+            e["sent"] = True
+            rec = {"seq": e["seq"]}
+            try:
+                v = e["inner"].result()
+                rec["usage"] = list(e["inner"].usage or ())
+                if e["gen"] is not None and getattr(v, "token_ids", None) and self.tok is not None:
+                    rec.update(kind="gen", ids=[list(map(int, t)) for t in v.token_ids],
+                               lp=[float(x) for x in v.cum_logprobs],
+                               dec=[[float(x) for x in d] for d in v.decision_logprobs] if v.decision_logprobs else None,
+                               pt=int(v.prompt_tokens), ct=int(v.cached_tokens))
+                elif e["gen"] is not None:
+                    rec.update(kind="text", texts=list(v.texts),
+                               dec=[[float(x) for x in d] for d in v.decision_logprobs] if v.decision_logprobs else None)
+                else:
+                    rec.update(kind="num", row=[float(x) for x in v])
+            except BackendError as err:
+                rec.update(kind="err", msg=str(err))
+            out.append(rec)
+        return out
+
+    def complete(self, rec: dict) -> None:
+        """Any rank of the replica: finishes the call a wire record names."""
+        from ..consensus.backend import GenResult
+
+        e = next((x for x in self._pending if x["seq"] == rec["seq"]), None)
+        if e is None:
+            return
+        self._pending.remove(e)
+        usage = tuple(rec.get("usage") or ()) or None
+        kind = rec["kind"]
+        if kind == "err":
+            return self._complete(e, "err", rec["msg"], None)
+        if kind == "gen":
+            v = GenResult(texts=[self._text_of(t) for t in rec["ids"]], token_ids=rec["ids"], cum_logprobs=rec["lp"],
+                          decision_logprobs=rec["dec"], prompt_tokens=rec["pt"], cached_tokens=rec["ct"])
+        elif kind == "text":
+            v = GenResult(texts=rec["texts"], decision_logprobs=rec["dec"])
+        else:
+            import numpy as np
+
+            v = np.asarray(rec["row"], dtype=np.float32)
+        self._complete(e, "ok", v, usage)
+
+    @property
+    def outstanding(self) -> int:
+        return len(self._pending)
 
     def engines(self) -> list:
         return self.local.engines() if self.local is not None else []
@@ -197,11 +357,15 @@ class DistributedEnsemble:
         # collective, capturable); the process-group communicator only bootstraps it.
         factory = backend_factory or (lambda spec, gc: build_backend(spec, self.device, wrap_group_comm(gc, self.device),
                                                                      gc.rank))
+        from ..utils.tokenizer import make_tokenizer
+
         for name in sorted(lay.owners):
             local = factory(cfg.models[name], lay.hosted[name]) if name in lay.hosted else None
+            mc = model_config_of(cfg.models[name])
+            # every rank of the replica holds the model's tokenizer: answers cross ranks as token ids
+            tok = make_tokenizer(cfg.models[name].tokenizer, mc.vocab_size) if backend_factory is None else None
             self.backends[name] = ShardedBackend(name, local, lay.owners[name], lay.replica_comm,
-                                                 embed_dim=model_config_of(cfg.models[name]).hidden_size,
-                                                 device=self.device)
+                                                 embed_dim=mc.hidden_size, device=self.device, tokenizer=tok)
         self.members = make_members(cfg, self.backends)
         judge_gpus = {d for m in cfg.members if m.role == "judge" for d in lay.devices_of.get(cfg.models[m.model].name, [])}
         other_gpus = {d for m in cfg.members if m.role != "judge" for d in lay.devices_of.get(cfg.models[m.model].name, [])}
@@ -250,6 +414,167 @@ class DistributedEnsemble:
         for part in self.comm.all_gather_object(mine):
             out.update(part or {})
         return out
+
+
+def _pack(obj) -> bytes:
+    """Wire form of a round's record: msgpack (numbers, strings, lists, maps; nothing executable)."""
+    import msgpack
+
+    return msgpack.packb(obj, use_bin_type=True, default=str)
+
+
+def _unpack(data: bytes):
+    import msgpack
+
+    return msgpack.unpackb(data, raw=False, strict_map_key=False)
+
+
+class LockstepDriver:
+    """Continuous serving for an ensemble that spans GPUs: every rank runs the SAME session pool
+    (protocol.SessionPool, strategies.VotePool / PhasedPool) over the replica's ShardedBackends
+    and the ranks advance in rounds. One round, on every rank:
+
+      1. step the engines this rank hosts for about ``quantum_s`` (decode steps run ahead of
+         their results, so the GPU keeps working through the rest of the round);
+      2. ONE exchange over the whole group (``Comm.all_gather_bytes``): rank 0 contributes the
+         questions that arrived since the last round (ticket, text) and the stop flag, every rank
+         the wire records of the member calls its engines finished (ShardedBackend.take_finished),
+         the first rank of every replica the answers its pool produced;
+      3. apply what came in, in rank order: complete the handles of the own replica's calls,
+         admit the new questions assigned to the own replica (ticket modulo replicas), then let
+         the pool advance its sessions (which queues their next member calls on the engines).
+
+    All ranks of a replica see the same completions in the same order, so their pools stay in
+    step without exchanging decisions; a question admitted in round r is decoding next to the
+    ones already in flight from round r + 1 on, and every finished answer reaches rank 0 one
+    round after its last member call ended. The reference consumes its members' replies as
+    they arrive (/root/reference/src/main.rs:259-291), one question at a time; this is that
+    loop for a node."""
+
+    def __init__(self, ens: "DistributedEnsemble", quantum_s: float = 0.02) -> None:
+        from ..consensus.backend import BackendStepper
+
+        self.ens, self.comm, self.quantum_s = ens, ens.comm, quantum_s
+        lay = ens.layout
+        self.replica, self.num_replicas = lay.replica, lay.num_replicas
+        self.lead = lay.replica >= 0 and lay.replica_comm.rank == 0
+        self.pool = None
+        self._local = None
+        if lay.replica >= 0:
+            if not callable(getattr(ens.strategy, "pool", None)):
+                raise RuntimeError(f"strategy {type(ens.strategy).__name__} has no continuous driver")
+            self.pool = ens.strategy.pool()
+            self.pool.stepper = _NoStep()                      # the rounds below advance the engines
+            hosted = [b.local for b in ens.backends.values() if b.local is not None]
+            self._local = BackendStepper(hosted)
+        self._ticket_of: Dict[int, int] = {}                   # pool ticket -> global ticket
+        self._answers: List[tuple] = []                        # (global ticket, ConsensusResult) awaiting the exchange
+        self.rounds = 0
+        self.stopped = False
+
+    def _step_engines(self) -> None:
+        if self._local is None:
+            return
+        t_end = time.perf_counter() + self.quantum_s
+        while any(b.outstanding for b in self.ens.backends.values() if b.local is not None):
+            if not self._local.step():
+                break                                          # everything in flight is still running
+            if time.perf_counter() >= t_end:
+                break
+
+    def round(self, new_questions: Sequence[tuple] = (), stop: bool = False) -> List[tuple]:
+        """One lock-step round. ``new_questions`` [(ticket, text)] and ``stop`` count on rank 0
+        only. Returns the (ticket, result record) pairs that reached this rank in the exchange
+        (every rank gets all of them; rank 0 is the one that hands them to callers)."""
+        with span("lockstep.step", "parallel"):
+            self._step_engines()
+        mine: Dict[str, object] = {}
+        if self.comm.rank == 0:
+            mine["new"] = [[int(t), str(q)] for t, q in new_questions]
+            mine["stop"] = bool(stop)
+        if self.replica >= 0:
+            done = {name: b.take_finished() for name, b in self.ens.backends.items()
+                    if b.local is not None and b.comm.rank == b.owner}
+            done = {k: v for k, v in done.items() if v}
+            if done:
+                mine["done"] = [self.replica, done]
+            if self.lead and self._answers:
+                mine["answers"] = [[t, _result_record(r)] for t, r in self._answers]
+                self._answers = []
+        with span("publish:round", "parallel", bytes=0):
+            parts = [(_unpack(p) if p else {}) for p in self.comm.all_gather_bytes(_pack(mine))]
+        self.rounds += 1
+        finished: List[tuple] = []
+        for part in parts:                                     # rank order: the same on every rank
+            for t, rec in part.get("answers", []):
+                finished.append((int(t), rec))
+            d = part.get("done")
+            if d and int(d[0]) == self.replica:
+                for name in sorted(d[1]):
+                    for rec in d[1][name]:
+                        self.ens.backends[name].complete(rec)
+        head = parts[0]
+        if self.pool is not None:
+            for t, q in head.get("new", []):
+                if int(t) % self.num_replicas == self.replica:
+                    self._ticket_of[self.pool.submit(q)] = int(t)
+            for pt, res in self.pool.pump():
+                self._answers.append((self._ticket_of.pop(pt), res))
+        if head.get("stop"):
+            self.stopped = True
+        return finished
+
+    @property
+    def busy(self) -> bool:
+        """This rank still has sessions in flight or answers to report."""
+        return bool(self.pool is not None and (self.pool.active or self._answers))
+
+    def follow(self) -> int:
+        """Loop of every rank but 0: rounds until rank 0 says stop. Returns the round count."""
+        while not self.stopped:
+            self.round()
+        return self.rounds
+
+
+class _NoStep:
+    """Stepper of a pool whose engines are advanced by LockstepDriver's rounds."""
+
+    @staticmethod
+    def step() -> bool:
+        return True
+
+
+def _result_record(r) -> dict:
+    """A ConsensusResult as plain data (what crosses ranks and what the front ends print)."""
+    return {"question": r.question, "answer": r.answer, "strategy": r.strategy, "rounds": int(r.rounds),
+            "member_calls": int(r.member_calls), "unanimous": bool(r.unanimous), "forced": bool(getattr(r, "forced", False)),
+            "agreement": float(getattr(r, "agreement", 0.0) or 0.0), "proposer": getattr(r, "proposer", None),
+            "latency_s": float(r.latency_s), "votes": _plain(getattr(r, "votes", None)),
+            "usage": _plain(getattr(r, "usage", None)), "extra": _plain(getattr(r, "extra", None))}
+
+
+def _plain(x):
+    import numpy as np
+
+    if isinstance(x, dict):
+        return {str(k): _plain(v) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_plain(v) for v in x]
+    if isinstance(x, np.generic):
+        return x.item()
+    if isinstance(x, np.ndarray):
+        return x.tolist()
+    return x
+
+
+def result_from_record(rec: dict):
+    from ..consensus.protocol import ConsensusResult
+
+    return ConsensusResult(question=rec["question"], answer=rec["answer"], strategy=rec["strategy"],
+                           rounds=rec["rounds"], member_calls=rec["member_calls"], unanimous=rec["unanimous"],
+                           forced=rec.get("forced", False), agreement=rec.get("agreement", 0.0),
+                           proposer=rec.get("proposer"), latency_s=rec["latency_s"], votes=rec.get("votes") or [],
+                           usage=rec.get("usage") or {}, extra=rec.get("extra") or {})
 
 
 class LeaderEnsemble:

@@ -329,3 +329,57 @@ def test_group_comm_first_contact_agreement_on_loopback(monkeypatch):
     out = run_loopback(2, build)
     assert all(r[0] == "LoopbackComm" and r[2] == "rank 1: timed out" for r in out), out
     assert sorted(FakeP2P.closed) == [0, 1]
+
+
+def _lockstep_serve(comm, cfg, questions, arrivals):
+    """Rank 0 feeds ``questions`` into a LockstepDriver, ``arrivals[i]`` = the round in which
+    question i arrives; returns {ticket: answer} on rank 0, the round count elsewhere."""
+    from llm_consensus_amd.parallel.ensemble_parallel import DistributedEnsemble, LockstepDriver
+
+    ens = DistributedEnsemble(cfg, comm, torch.device("cpu"))
+    drv = LockstepDriver(ens, quantum_s=0.0)
+    if comm.rank != 0:
+        return drv.follow()
+    got, rnd = {}, 0
+    while len(got) < len(questions):
+        new = [(i, q) for i, q in enumerate(questions) if arrivals[i] == rnd]
+        for t, rec in drv.round(new):
+            got[t] = rec["answer"]
+        rnd += 1
+        assert rnd < 5000, "lock-step rounds do not converge"
+    drv.round(stop=True)
+    return got
+
+
+def test_lockstep_driver_late_admission_equals_wave_driver_three_ranks():
+    """Continuous serving of an ensemble with one model per GPU: questions that arrive while
+    others are in flight join at the next round; the answers are those of the wave driver."""
+    from llm_consensus_amd.app import build_ensemble
+
+    cfg = _spread_cfg()
+    want = [r.answer for r in build_ensemble(cfg, torch.device("cpu")).ask_many(QUESTIONS)]
+    arrivals = [0, 0, 3, 5, 9, 9][:len(QUESTIONS)] + [12] * max(0, len(QUESTIONS) - 6)
+    res = run_loopback(3, lambda comm: _lockstep_serve(comm, cfg, QUESTIONS, arrivals))
+    assert [res[0][i] for i in range(len(QUESTIONS))] == want
+    assert res[1] == res[2] and res[1] > 3               # followers ran the same number of rounds
+
+
+def test_lockstep_driver_two_phase_strategy_with_tensor_parallel_judge_five_ranks():
+    """The judge workload's shape: four... two proposers on their own ranks and a TP=2 judge, served
+    continuously (PhasedPool under the lock-step rounds)."""
+    from llm_consensus_amd.app import build_ensemble
+
+    cfg = _spread_cfg("judge_logprob", judge_tp=2)
+    want = [r.answer for r in build_ensemble(cfg, torch.device("cpu")).ask_many(QUESTIONS[:4])]
+    res = run_loopback(5, lambda comm: _lockstep_serve(comm, cfg, QUESTIONS[:4], [0, 2, 2, 6]))
+    assert [res[0][i] for i in range(4)] == want
+
+
+def test_lockstep_driver_shards_tickets_over_replicas():
+    from llm_consensus_amd.app import build_ensemble
+
+    cfg = _spread_cfg()
+    want = [r.answer for r in build_ensemble(cfg, torch.device("cpu")).ask_many(QUESTIONS)]
+    res = run_loopback(6, lambda comm: _lockstep_serve(comm, cfg, QUESTIONS, [0, 0, 1, 1, 4, 4][:len(QUESTIONS)]
+                                                       + [6] * max(0, len(QUESTIONS) - 6)))
+    assert [res[0][i] for i in range(len(QUESTIONS))] == want
