@@ -579,9 +579,70 @@ def run_configured(ctx: Ctx, cfg, per_replica: int, prompt_len: int, steps: int,
         used = ens.collectives()
         if used:
             sec["collectives"] = used
+    if not ctx.a.skip_stream:
+        sq = closed_loop_configured(ctx, ens, rng, 2 * n_global, 4 * n_global, prompt_len)
+        if sq:
+            sec["standing_queue"] = sq
     del ens, ask
     ctx.free()
     return sec
+
+
+def closed_loop_configured(ctx: Ctx, ens, rng, in_flight: int, n_total: int, prompt_len: int):
+    """The configured ensemble as a service under load: ``in_flight`` questions are kept in the
+    engines at all times, every finished question is replaced by a new one. One process: the
+    strategy's pool (SessionPool / VotePool / PhasedPool). Several ranks: lock-step rounds
+    (parallel.ensemble_parallel.LockstepDriver), rank 0 feeding the questions; a question is
+    sent to the other ranks in the round after it arrives and its answer returns in the round
+    after its last member call, both inside the measured latency."""
+    from llm_consensus_amd.workloads import make_questions
+
+    strat = getattr(ens, "strategy", None)
+    if ctx.world == 1 and not callable(getattr(strat, "pool", None)):
+        return None
+    qs = make_questions(rng, n_total, prompt_len)
+    lat, n_done = [], 0
+    ctx.comm.barrier()
+    ctx.sync()
+    t0 = time.perf_counter()
+    if ctx.world == 1:
+        pool = strat.pool()
+        nxt = 0
+        while nxt < min(in_flight, n_total):
+            pool.submit(qs[nxt])
+            nxt += 1
+        while pool.active:
+            for _, r in pool.pump():
+                n_done += 1
+                lat.append(r.latency_s * 1e3)
+                if nxt < n_total:
+                    pool.submit(qs[nxt])
+                    nxt += 1
+        mode = "closed loop: a finished question is replaced at the next engine step"
+    else:
+        from llm_consensus_amd.parallel.ensemble_parallel import LockstepDriver
+
+        drv = LockstepDriver(ens)
+        if ctx.rank != 0:
+            drv.follow()
+        else:
+            sent, nxt = {}, 0
+            while n_done < n_total:
+                new = []
+                while nxt < n_total and nxt - n_done < in_flight:
+                    new.append((nxt, qs[nxt]))
+                    sent[nxt] = time.perf_counter()
+                    nxt += 1
+                for t, _ in drv.round(new):
+                    n_done += 1
+                    lat.append((time.perf_counter() - sent.pop(t)) * 1e3)
+            drv.round(stop=True)
+        mode = "closed loop in lock-step rounds over all ranks: a finished question is replaced in the next round"
+    ctx.sync()
+    ctx.comm.barrier()
+    el = ctx.comm.max_float(time.perf_counter() - t0)
+    return {"mode": mode, "questions_in_flight": in_flight, "questions": n_total, "value": round(n_total / el, 3),
+            "unit": "answers/s", "p50_latency_ms": pct(lat, 50), "p95_latency_ms": pct(lat, 95)}
 
 
 # ------------------------------------------------------------------------------------ isolation

@@ -96,9 +96,17 @@ def main(argv: Optional[list] = None) -> int:
     ap.add_argument("--no-warm-up", action="store_true",
                     help="skip the start-up warm-up (kernel loading, decode graph recording); the first "
                          "questions then pay for it")
+    ap.add_argument("--gpus", type=int, default=None,
+                    help="run as this many ranks, one per GPU, started by this command (default: the GPUs one "
+                         "replica of the configured ensemble is planned for when several are visible; with "
+                         "--device cpu the ranks are CPU processes)")
+    ap.add_argument("--batched", action="store_true",
+                    help="several ranks: answer each batch as one wave instead of serving continuously")
     ap.add_argument("--distributed", action="store_true",
-                    help="one process per GPU under torch.distributed.run: members are placed over the "
-                         "node's GPUs by the planner; rank 0 owns the terminal")
+                    help="this process is ONE rank of a group started by a launcher (this command with --gpus, "
+                         "or torch.distributed.run): members are placed over the ranks by the planner; rank 0 "
+                         "owns the terminal")
+    argv = sys.argv[1:] if argv is None else list(argv)
     args = ap.parse_args(argv)
 
     cfg: ConsensusConfig = load_config(args.config)
@@ -113,6 +121,19 @@ def main(argv: Optional[list] = None) -> int:
     if args.strategy:
         cfg.strategy = args.strategy
         cfg.validate()
+    from .parallel import launch
+
+    if not args.distributed and not launch.under_launcher():
+        # This process only supervises when the ensemble spans GPUs: it starts the ranks before it
+        # has touched a GPU itself; rank 0 inherits the terminal.
+        n = launch.ranks_for(cfg, args.gpus, args.device, replicate=bool(args.questions))
+        if n > 1:
+            return launch.launch_ranks("llm_consensus_amd.cli", launch.strip_flag(argv, "--gpus") + ["--distributed"], n)
+        packed = launch.warn_if_packed(cfg, n, args.device)
+        if packed:
+            print(packed, file=sys.stderr, flush=True)
+    elif launch.under_launcher():
+        args.distributed = True
     import torch
 
     from .app import build_ensemble
@@ -120,14 +141,12 @@ def main(argv: Optional[list] = None) -> int:
     device = torch.device(args.device) if args.device else None
     leader = None
     if args.distributed:
-        from .parallel.ensemble_parallel import DistributedEnsemble, LeaderEnsemble, follow, init_distributed
+        from .parallel.ensemble_parallel import init_distributed, serve_distributed
 
         comm, device = init_distributed(device.type if device else None)
-        dist_ens = DistributedEnsemble(cfg, comm, device)
-        if comm.rank != 0:
-            follow(dist_ens)
+        ensemble = leader = serve_distributed(cfg, comm, device, continuous=not args.batched)
+        if ensemble is None:              # a follower rank: it has served until rank 0 closed
             return 0
-        ensemble = leader = LeaderEnsemble(dist_ens)
     else:
         ensemble = build_ensemble(cfg, device)
     if not args.no_warm_up:

@@ -482,16 +482,20 @@ class LockstepDriver:
             if time.perf_counter() >= t_end:
                 break
 
-    def round(self, new_questions: Sequence[tuple] = (), stop: bool = False) -> List[tuple]:
-        """One lock-step round. ``new_questions`` [(ticket, text)] and ``stop`` count on rank 0
-        only. Returns the (ticket, result record) pairs that reached this rank in the exchange
-        (every rank gets all of them; rank 0 is the one that hands them to callers)."""
+    def round(self, new_questions: Sequence[tuple] = (), stop: bool = False, control: Optional[dict] = None) -> List[tuple]:
+        """One lock-step round. ``new_questions`` [(ticket, text)], ``stop`` and ``control`` count
+        on rank 0 only (``control`` = {"op": "warm_up", "kw": {...}}: every rank runs that
+        ensemble-wide operation at the end of the round). Returns the (ticket, result record)
+        pairs that reached this rank in the exchange (every rank gets all of them; rank 0 is the
+        one that hands them to callers)."""
         with span("lockstep.step", "parallel"):
             self._step_engines()
         mine: Dict[str, object] = {}
         if self.comm.rank == 0:
             mine["new"] = [[int(t), str(q)] for t, q in new_questions]
             mine["stop"] = bool(stop)
+            if control:
+                mine["ctl"] = control
         if self.replica >= 0:
             done = {name: b.take_finished() for name, b in self.ens.backends.items()
                     if b.local is not None and b.comm.rank == b.owner}
@@ -520,6 +524,9 @@ class LockstepDriver:
                     self._ticket_of[self.pool.submit(q)] = int(t)
             for pt, res in self.pool.pump():
                 self._answers.append((self._ticket_of.pop(pt), res))
+        ctl = head.get("ctl")
+        if ctl and ctl.get("op") == "warm_up":
+            self.ens.warm_up(**(ctl.get("kw") or {}))
         if head.get("stop"):
             self.stopped = True
         return finished
@@ -577,6 +584,80 @@ def result_from_record(rec: dict):
                            usage=rec.get("usage") or {}, extra=rec.get("extra") or {})
 
 
+class LockstepEnsemble:
+    """What the front ends hold on rank 0 of a distributed ensemble served continuously: the
+    ``ask`` / ``ask_many`` / ``warm_up`` / ``stats`` / ``close`` of app.Ensemble, carried out by
+    lock-step rounds (the other ranks sit in ``LockstepDriver.follow``). ``submit`` / ``poll``
+    are the non-blocking form the HTTP server's driver loop uses."""
+
+    def __init__(self, dist_ensemble: DistributedEnsemble, quantum_s: float = 0.02) -> None:
+        self.inner = dist_ensemble
+        self.config = dist_ensemble.config
+        self.members = getattr(dist_ensemble, "members", [])
+        self.backends: Dict[str, Backend] = {}       # member models are not individually addressable here
+        self.driver = LockstepDriver(dist_ensemble, quantum_s)
+        self._next = 0
+        self._new: List[tuple] = []
+        self.in_flight = 0
+
+    def submit(self, question: str) -> int:
+        t = self._next
+        self._next += 1
+        self._new.append((t, question))
+        self.in_flight += 1
+        return t
+
+    def poll(self) -> List[tuple]:
+        """One round; returns [(ticket, ConsensusResult)] of the questions answered in it."""
+        new, self._new = self._new, []
+        out = [(t, result_from_record(rec)) for t, rec in self.driver.round(new)]
+        self.in_flight -= len(out)
+        return out
+
+    def ask_many(self, questions: Sequence[str]) -> List[Any]:
+        tickets = [self.submit(q) for q in questions]
+        got: Dict[int, Any] = {}
+        while any(t not in got for t in tickets):
+            got.update(dict(self.poll()))
+        return [got[t] for t in tickets]
+
+    def ask(self, question: str):
+        return self.ask_many([question])[0]
+
+    def warm_up(self, **kw):
+        self.driver.round(control={"op": "warm_up", "kw": kw})
+        return {}
+
+    def stats(self) -> Dict[str, Dict[str, float]]:
+        return self.inner.stats()
+
+    def record(self, results) -> None:
+        """Ensemble-level counters hook of the server's continuous loop (kept per engine here)."""
+
+    def close(self) -> None:
+        while self.in_flight > 0:
+            self.poll()
+        self.driver.round(stop=True)
+
+
+def serve_distributed(cfg, comm: Comm, device, continuous: bool = True):
+    """Builds the distributed ensemble on this rank. Rank 0 gets the front-end object
+    (LockstepEnsemble when the strategy can be served continuously, LeaderEnsemble otherwise);
+    every other rank serves until rank 0 closes and gets None."""
+    dist_ens = DistributedEnsemble(cfg, comm, device)
+    lockstep = continuous and callable(getattr(dist_ens.strategy, "pool", None)) if dist_ens.strategy is not None \
+        else continuous
+    # ranks that are idle under the plan have no strategy; rank 0 decides for everybody
+    lockstep = bool(comm.broadcast_object(lockstep if comm.rank == 0 else None, 0))
+    if comm.rank != 0:
+        if lockstep:
+            LockstepDriver(dist_ens).follow()
+        else:
+            follow(dist_ens)
+        return None
+    return LockstepEnsemble(dist_ens) if lockstep else LeaderEnsemble(dist_ens)
+
+
 class LeaderEnsemble:
     """Front-end view of a DistributedEnsemble on rank 0: the REPL / HTTP server calls
     ``ask_many`` here, the question batch is broadcast to the follower ranks (which sit in
@@ -623,9 +704,12 @@ def follow(dist_ensemble: DistributedEnsemble) -> int:
 
 
 def init_distributed(device_type: Optional[str] = None):
-    """Process-group bring-up from torchrun's environment: RCCL ("nccl") with one GPU per
-    process when GPUs are present, gloo otherwise. Returns (comm, device)."""
+    """Process-group bring-up from the launcher's environment (RANK / LOCAL_RANK / WORLD_SIZE /
+    MASTER_*): RCCL ("nccl") with one GPU per process when GPUs are present, gloo otherwise.
+    The collective timeout is a day: a front end's ranks wait in a collective while rank 0 waits
+    for the next question. Returns (comm, device)."""
     import os
+    from datetime import timedelta
 
     import torch.distributed as dist
 
@@ -637,8 +721,8 @@ def init_distributed(device_type: Optional[str] = None):
         local = int(os.environ.get("LOCAL_RANK", "0"))
         torch.cuda.set_device(local)
         device = torch.device("cuda", local)
-        dist.init_process_group("nccl", device_id=device)
+        dist.init_process_group("nccl", device_id=device, timeout=timedelta(hours=24))
     else:
         device = torch.device("cpu")
-        dist.init_process_group("gloo")
+        dist.init_process_group("gloo", timeout=timedelta(hours=24))
     return make_comm(dist, device), device

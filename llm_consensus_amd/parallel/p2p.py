@@ -471,4 +471,7 @@ def _describe(comm: Comm) -> str:
         return "rccl"
     if getattr(comm, "staged", False):
         return "gloo (host-staged)"
+    dist = getattr(comm, "dist", None)
+    if dist is not None:
+        return str(dist.get_backend(getattr(comm, "group", None))).lower()
     return type(comm).__name__

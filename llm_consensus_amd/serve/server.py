@@ -237,7 +237,53 @@ class ConsensusServer:
         if j.chunks is not None:
             j.chunks.put(None)
 
+    def _drive_lockstep(self) -> None:
+        """An ensemble that spans several ranks (parallel.ensemble_parallel.LockstepEnsemble): every
+        pass of this loop is one lock-step round of the whole group. New questions travel to the
+        other ranks in the round's exchange and join the sessions in flight; answers come back in
+        the exchange of the round after their last member call. While nothing is in flight a
+        round is the group's heartbeat."""
+        ens = self.ensemble
+        tickets: Dict[int, _Job] = {}
+        while not self._stop.is_set():
+            new: List[_Job] = []
+            if not tickets:
+                try:
+                    new.append(self.jobs.get(timeout=0.05))
+                except queue.Empty:
+                    pass
+            while len(tickets) + len(new) < 4 * self.max_batch:
+                try:
+                    new.append(self.jobs.get_nowait())
+                except queue.Empty:
+                    break
+            if new:
+                with self._lock:
+                    self.counters["batches_total"] += 1
+                    self.counters["batched_requests_total"] += len(new)
+            for j in new:
+                if j.kind != "consensus":
+                    j.error = "member models are not individually addressable when the ensemble spans several ranks"
+                    self._finish(j)
+                else:
+                    tickets[ens.submit(j.text)] = j
+            try:
+                finished = ens.poll()
+            except Exception as e:  # noqa: BLE001  never let the driver die with waiters parked on it
+                log.error("lock-step round failed: %s", e)
+                for j in tickets.values():
+                    j.error = f"{type(e).__name__}: {e}"
+                    self._finish(j)
+                raise
+            for t, res in finished:
+                j = tickets.pop(t, None)
+                if j is not None:
+                    j.result = res
+                    j.done.set()
+
     def _drive(self) -> None:
+        if callable(getattr(self.ensemble, "poll", None)) and callable(getattr(self.ensemble, "submit", None)):
+            return self._drive_lockstep()
         if self._continuous_ok():
             return self._drive_continuous()
         while not self._stop.is_set():
@@ -555,26 +601,46 @@ def main(argv: Optional[list] = None) -> int:
     ap.add_argument("--port", type=int, default=8000)
     ap.add_argument("--max-batch", type=int, default=64)
     ap.add_argument("--batch-window-ms", type=float, default=5.0)
+    ap.add_argument("--gpus", type=int, default=None,
+                    help="run as this many ranks, one per GPU, started by this command (default: every replica "
+                         "of the configured ensemble that the visible GPUs hold)")
+    ap.add_argument("--device", help="cuda or cpu (default: GPU when present)")
     ap.add_argument("--distributed", action="store_true",
-                    help="one process per GPU under torch.distributed.run; rank 0 serves HTTP")
+                    help="this process is ONE rank of a group started by a launcher (this command with --gpus, "
+                         "or torch.distributed.run); rank 0 serves HTTP")
     ap.add_argument("--no-warm-up", action="store_true",
                     help="do not record the decode graphs before the socket opens (the first requests of every "
                          "batch shape then pay for it)")
     ap.add_argument("--batched", action="store_true",
                     help="answer in closed batches even where the continuous driver applies")
+    import sys
+
+    argv = sys.argv[1:] if argv is None else list(argv)
     args = ap.parse_args(argv)
     cfg = load_config(args.config)
-    if args.distributed:
-        from ..parallel.ensemble_parallel import DistributedEnsemble, LeaderEnsemble, follow, init_distributed
+    from ..parallel import launch
 
-        comm, device = init_distributed()
-        dist_ens = DistributedEnsemble(cfg, comm, device)
-        if comm.rank != 0:
-            follow(dist_ens)
+    if not args.distributed and not launch.under_launcher():
+        n = launch.ranks_for(cfg, args.gpus, args.device, replicate=True)
+        if n > 1:
+            return launch.launch_ranks("llm_consensus_amd.serve.server",
+                                       launch.strip_flag(argv, "--gpus") + ["--distributed"], n)
+        packed = launch.warn_if_packed(cfg, n, args.device)
+        if packed:
+            print(packed, file=sys.stderr, flush=True)
+    elif launch.under_launcher():
+        args.distributed = True
+    if args.distributed:
+        from ..parallel.ensemble_parallel import init_distributed, serve_distributed
+
+        comm, device = init_distributed(args.device)
+        ens = serve_distributed(cfg, comm, device, continuous=not args.batched)
+        if ens is None:
             return 0
-        ens = LeaderEnsemble(dist_ens)
     else:
-        ens = build_ensemble(cfg)
+        import torch
+
+        ens = build_ensemble(cfg, torch.device(args.device) if args.device else None)
     if not args.no_warm_up:
         ens.warm_up()
     try:

@@ -133,7 +133,9 @@ def test_isolated_section_reports_which_collectives_it_used():
     p = run_bench(["--gpus", "2", "--workload", "E"] + TINY)
     assert p.returncode == 0, p.stderr[-3000:]
     out = json_line(p)
-    assert out["moe_medoid"]["collectives"].startswith("p2p") and out["value"] == out["moe_medoid"]["value"]
+    # per sharded model: the transport its group ended up on (CPU ranks: the gloo process group, eager steps)
+    assert coll(out["moe_medoid"]).startswith("gloo") and "eager" in coll(out["moe_medoid"])
+    assert out["value"] == out["moe_medoid"]["value"]
 
 
 def test_four_ranks_shard_the_judge_four_ways_next_to_the_proposers():
@@ -213,3 +215,17 @@ def test_four_ranks_rehearse_the_sharded_workloads_on_one_gpu():
     assert d.get("value", 0) > 0 and d["judge_tp"] == 4, d
     assert e.get("value", 0) > 0 and e["expert_parallel"] == 4 and e["ep_mode"] == "a2a", e
     assert all(coll(x).startswith("p2p") for x in (sp, d, e))
+
+
+def test_sharded_workloads_report_a_standing_queue_in_lock_step_rounds():
+    """D and E as services under load: one process drives the strategy's pool; two ranks (TP=2
+    judge, EP=2 experts) are driven in lock-step rounds with rank 0 feeding the questions."""
+    args = [x for x in TINY if x != "--skip-stream"] + ["--workload", "D,E", "--poisson-load", "0"]
+    for gpus in (1, 2):
+        p = run_bench(args + ["--gpus", str(gpus)], timeout=600)
+        assert p.returncode == 0, p.stderr[-3000:]
+        out = json_line(p)
+        for key in ("judge_consensus", "moe_medoid"):
+            sq = out[key]["standing_queue"]
+            assert sq["value"] > 0 and sq["questions"] == 4 * 2 * gpus and sq["p50_latency_ms"] > 0, (gpus, key, sq)
+            assert ("lock-step" in sq["mode"]) == (gpus == 2)
