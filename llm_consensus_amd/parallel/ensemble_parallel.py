@@ -467,6 +467,15 @@ class LockstepDriver:
             self.pool.stepper = _NoStep()                      # the rounds below advance the engines
             hosted = [b.local for b in ens.backends.values() if b.local is not None]
             self._local = BackendStepper(hosted)
+            # A rank that holds a shard of a tensor / expert parallel model advances its engines
+            # exactly once per round: the ranks of such a group must launch the same steps (their
+            # kernels wait for each other), and a rank that ran ahead on its own clock would block
+            # on a step its peer only launches after the exchange both of them have to join.
+            self._sharded = any(getattr(getattr(e, "model", None), "tp_size", 1) > 1
+                                or getattr(getattr(e, "model", None), "ep_size", 1) > 1
+                                for b in hosted for e in ([b.engine] if hasattr(b, "engine") else []))
+        if self.pool is None:
+            self._sharded = False
         self._ticket_of: Dict[int, int] = {}                   # pool ticket -> global ticket
         self._answers: List[tuple] = []                        # (global ticket, ConsensusResult) awaiting the exchange
         self.rounds = 0
@@ -479,7 +488,7 @@ class LockstepDriver:
         while any(b.outstanding for b in self.ens.backends.values() if b.local is not None):
             if not self._local.step():
                 break                                          # everything in flight is still running
-            if time.perf_counter() >= t_end:
+            if self._sharded or time.perf_counter() >= t_end:
                 break
 
     def round(self, new_questions: Sequence[tuple] = (), stop: bool = False, control: Optional[dict] = None) -> List[tuple]:

@@ -229,3 +229,19 @@ def test_sharded_workloads_report_a_standing_queue_in_lock_step_rounds():
             sq = out[key]["standing_queue"]
             assert sq["value"] > 0 and sq["questions"] == 4 * 2 * gpus and sq["p50_latency_ms"] > 0, (gpus, key, sq)
             assert ("lock-step" in sq["mode"]) == (gpus == 2)
+
+
+@pytest.mark.gpu
+def test_two_ranks_serve_the_sharded_workloads_in_lock_step_rounds_on_one_gpu():
+    """--share-gpu with the standing-queue sections on: the TP=2 judge (peer-to-peer kernels, decode
+    steps recorded as hipGraphs and launched ahead of their results) and the EP=2 MoE are served
+    continuously, both ranks advancing in lock-step rounds with rank 0 feeding the questions."""
+    args = [x for x in TINY if x not in ("--device", "cpu", "--skip-stream")]
+    args += ["--gpus", "2", "--share-gpu", "--workload", "D,E", "--poisson-load", "0"]
+    p = run_bench(args, env={"HSA_ENABLE_IPC_MODE_LEGACY": "0"}, timeout=420)
+    assert p.returncode == 0, p.stderr[-3000:]
+    out = json_line(p)
+    for key in ("judge_consensus", "moe_medoid"):
+        sq = out[key]["standing_queue"]
+        assert sq["value"] > 0 and "lock-step" in sq["mode"] and sq["questions"] == 16, (key, sq)
+        assert coll(out[key]).startswith("p2p"), out[key]
