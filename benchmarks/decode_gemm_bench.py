@@ -63,8 +63,7 @@ def main():
                 elif v == "tile":
                     ops.WS_MAX_M, ops.GEMM256_MIN_TILES = 0, -1
                     fns = [lambda lw=lw: ops.linear(X, lw) for lw in lws]
-                elif v in ("ws", "panel"):   # force one of the two decode kernels
-                    ops.DECODE_KERNEL = v
+                elif v == "panel":           # the decode kernel with its split-K slabs left unreduced
                     fns = [lambda lw=lw: ops.linear(X, lw, defer_reduce=True) for lw in lws]
                 elif v == "g256":
                     if M < 256 or lws[0].n_pad % 256:
@@ -80,7 +79,6 @@ def main():
                 except Exception as ex:  # noqa: BLE001
                     row[v + "_err"] = str(ex)[:80]
                 ops.WS_MAX_M, ops.GEMM256_MIN_TILES = 256, 1
-                ops.DECODE_KERNEL = "panel"
             out.append(row)
             print(row, flush=True)
         del Ws, lws

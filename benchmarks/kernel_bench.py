@@ -54,9 +54,9 @@ def bench_gemm(results):
                 continue
             X = (torch.randn(M, K, device=DEV) * 0.5).bfloat16()
             row = {"op": "linear", "M": M, "N": N, "K": K}
-            for name, ws_max, g256 in (("ws", 256, -1), ("k1", 256, -1), ("k2", 256, -1), ("k4", 256, -1),
+            for name, ws_max, g256 in (("panel", 256, -1), ("k1", 256, -1), ("k2", 256, -1), ("k4", 256, -1),
                                        ("tile", 0, -1), ("g256", 0, 0)):
-                if name in ("ws", "k1", "k2", "k4") and M > 256:
+                if name in ("panel", "k1", "k2", "k4") and M > 256:
                     continue
                 if name[0] == "k" and (M > 64 or N > 40960):
                     continue

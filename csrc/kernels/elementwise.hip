@@ -1,5 +1,6 @@
-// Memory-bound row kernels: embedding gather, RMSNorm (+ fused residual add), SwiGLU,
-// KV block copy, embedding pooling. All use 16-byte per-lane accesses and one wave per
+// Memory-bound row kernels: embedding gather (also the row gather and the device-side token
+// feed), RMSNorm (+ fused residual add and split-K slab sum), KV block copy, embedding pooling,
+// small fp32 helpers (accumulate, column padding, column concatenation). SwiGLU is a GEMM epilogue. All use 16-byte per-lane accesses and one wave per
 // row; none of them exists in the reference (its model is remote,
 // /root/reference/src/main.rs:82-86).
 #include "common.h"
@@ -120,42 +121,6 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(bf16_t* __restrict__ h, co
                                               bf16_to_f32(static_cast<bf16_t>(g[i][j]))));
       *reinterpret_cast<bf16x8*>(yrow + c * 8) = o;
     }
-  }
-}
-
-// act[t, i] = silu(gu[t, i]) * gu[t, dff + i]   (gate and up halves stored side by side)
-__global__ void swiglu_kernel(const bf16_t* __restrict__ gu, bf16_t* __restrict__ act, int T, int dff) {
-  const size_t nchunk = static_cast<size_t>(T) * (dff / 8);
-  for (size_t c = blockIdx.x * static_cast<size_t>(blockDim.x) + threadIdx.x; c < nchunk;
-       c += static_cast<size_t>(gridDim.x) * blockDim.x) {
-    const size_t t = c / (dff / 8), i = c % (dff / 8);
-    const bf16_t* g = gu + t * (2 * static_cast<size_t>(dff)) + i * 8;
-    bf16x8 a = *reinterpret_cast<const bf16x8*>(g);
-    bf16x8 b = *reinterpret_cast<const bf16x8*>(g + dff);
-    bf16x8 o;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const float x = bf16_to_f32(static_cast<bf16_t>(a[j]));
-      const float u = bf16_to_f32(static_cast<bf16_t>(b[j]));
-      o[j] = static_cast<short>(f32_to_bf16(x / (1.f + __expf(-x)) * u));
-    }
-    *reinterpret_cast<bf16x8*>(act + t * static_cast<size_t>(dff) + i * 8) = o;
-  }
-}
-
-// y = a + b (bf16), used for residual adds outside the fused norm.
-__global__ void add_kernel(const bf16_t* __restrict__ a, const bf16_t* __restrict__ b,
-                           bf16_t* __restrict__ y, size_t nchunk) {
-  for (size_t c = blockIdx.x * static_cast<size_t>(blockDim.x) + threadIdx.x; c < nchunk;
-       c += static_cast<size_t>(gridDim.x) * blockDim.x) {
-    bf16x8 x = reinterpret_cast<const bf16x8*>(a)[c];
-    bf16x8 z = reinterpret_cast<const bf16x8*>(b)[c];
-    bf16x8 o;
-#pragma unroll
-    for (int j = 0; j < 8; ++j)
-      o[j] = static_cast<short>(
-          f32_to_bf16(bf16_to_f32(static_cast<bf16_t>(x[j])) + bf16_to_f32(static_cast<bf16_t>(z[j]))));
-    reinterpret_cast<bf16x8*>(y)[c] = o;
   }
 }
 
@@ -313,27 +278,6 @@ LC_EXPORT int lc_rmsnorm(void* h, const void* delta, const void* w, void* y, int
     else LC_RMS(16, 1, grid);
   }
 #undef LC_RMS
-  LC_RETURN_LAST_ERROR();
-}
-
-LC_EXPORT int lc_swiglu(const void* gu, void* act, int T, int dff, hipStream_t stream) {
-  if (T <= 0) return 0;
-  if (dff % 8) return -1;
-  const size_t nchunk = static_cast<size_t>(T) * (dff / 8);
-  const int grid = static_cast<int>(std::min<size_t>((nchunk + 255) / 256, 4096));
-  swiglu_kernel<<<dim3(grid), dim3(256), 0, stream>>>(static_cast<const bf16_t*>(gu),
-                                                      static_cast<bf16_t*>(act), T, dff);
-  LC_RETURN_LAST_ERROR();
-}
-
-LC_EXPORT int lc_add(const void* a, const void* b, void* y, long long n, hipStream_t stream) {
-  if (n <= 0) return 0;
-  if (n % 8) return -1;
-  const size_t nchunk = static_cast<size_t>(n) / 8;
-  const int grid = static_cast<int>(std::min<size_t>((nchunk + 255) / 256, 4096));
-  add_kernel<<<dim3(grid), dim3(256), 0, stream>>>(static_cast<const bf16_t*>(a),
-                                                   static_cast<const bf16_t*>(b),
-                                                   static_cast<bf16_t*>(y), nchunk);
   LC_RETURN_LAST_ERROR();
 }
 

@@ -10,13 +10,12 @@
 // activation fragment the B operand (cols = m), i.e. the kernels compute Y^T tiles.
 // A lane then owns 4 consecutive n of one row m: an 8-byte bf16 store.
 //
-// Two kernels:
-//   * gemm_tile_kernel  -- M >= ~256 (prefill): 128x128x64 block tile, 4 waves (2x2),
-//     both operands staged global->LDS with global_load_lds_dwordx4, double-buffered.
-//   * wsgemm_kernel     -- M <= 256 (decode): weight-streaming; every wave streams its
-//     own n-tiles of W straight into registers (read once, never shared, so no LDS),
-//     activations are shared through LDS; optional split-K over blockIdx.y with fp32
-//     partial slabs reduced by splitk_reduce_kernel.
+// Kernels of this file:
+//   * gemm_tile_kernel    -- 128x128x64 block tile, 4 waves (2x2), both operands staged
+//     global->LDS with global_load_lds_dwordx4, double-buffered: outputs whose width is not
+//     a multiple of 256 (tiny models); everything else goes to gemm256.hip / gemm_panel.hip.
+//   * gemm_grouped_kernel -- the same tile per expert over ragged row groups (MoE).
+//   * splitk_reduce_kernel -- sums the fp32 slabs of a split-K GEMM.
 // Epilogues: bias add, bf16 or fp32 store, fused SwiGLU (gate/up n-tiles interleaved).
 #include "gemm_common.h"
 
@@ -205,108 +204,6 @@ __global__ __launch_bounds__(256) void gemm_grouped_kernel(const bf16_t* __restr
     }
 }
 
-// ---------------------------------------------------------------------------------
-// Weight-streaming kernel for M <= 16*MT. Block = 4 waves; wave w owns NTW consecutive
-// n-tiles and streams their fragments along K straight into registers, one iteration
-// (KPI k-tiles) ahead. The X slice [16*MT, 32*KPI] of each iteration is staged in LDS
-// once per block and read by all four waves. blockIdx.y selects the K split.
-// ---------------------------------------------------------------------------------
-template <int MT, int NTW, int KPI, int EPI>
-__global__ __launch_bounds__(256) void wsgemm_kernel(const bf16_t* __restrict__ Wp,
-                                                     const bf16_t* __restrict__ X, void* __restrict__ Y,
-                                                     const bf16_t* __restrict__ bias, int M, int N, int K,
-                                                     int ldy, int kt_per_split) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int STAGE = MT * KPI * 1024;
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int KT = K / 32;
-  const int nt0 = (blockIdx.x * 4 + wave) * NTW;
-  const int kt_begin = blockIdx.y * kt_per_split;
-  const int kt_end = kt_begin + kt_per_split;
-  const int iters = (kt_per_split + KPI - 1) / KPI;  // the last iteration may be partial
-
-  auto stage_x = [&](char* stage, int kt0) {
-    // MT*KPI pieces of 1 KiB, dealt round-robin to the 4 waves.
-    for (int p = wave; p < MT * KPI; p += 4) {
-      const int mt = p / KPI, kt = p % KPI;
-      int row = mt * 16 + (lane & 15);
-      row = row < M ? row : M - 1;
-      // k-tiles past the split's end are clamped: their weights are zero, X only has to be finite
-      const int ktc = kt0 + kt < kt_end ? kt0 + kt : kt_end - 1;
-      const bf16_t* src = X + static_cast<size_t>(row) * K + ktc * 32 + 8 * (lane >> 4);
-      __builtin_amdgcn_global_load_lds(LC_GLOBAL_PTR(src), LC_LDS_PTR(stage + p * 1024), 16, 0, 0);
-    }
-  };
-  auto load_w = [&](bf16x8 (&w)[NTW][KPI], int kt0) {
-#pragma unroll
-    for (int n = 0; n < NTW; ++n)
-#pragma unroll
-      for (int kt = 0; kt < KPI; ++kt) {
-        if (kt0 + kt < kt_end)
-          w[n][kt] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(
-              Wp + (static_cast<size_t>(nt0 + n) * KT + (kt0 + kt)) * 512 + lane * 8));
-        else
-          w[n][kt] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
-      }
-  };
-
-  f32x4 acc[NTW][MT];
-#pragma unroll
-  for (int n = 0; n < NTW; ++n)
-#pragma unroll
-    for (int m = 0; m < MT; ++m) acc[n][m] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  bf16x8 wa[NTW][KPI], wb[NTW][KPI];
-  stage_x(smem, kt_begin);
-  load_w(wa, kt_begin);
-  __syncthreads();
-
-  auto compute = [&](const char* cur, bf16x8 (&w)[NTW][KPI]) {
-#pragma unroll
-    for (int kt = 0; kt < KPI; ++kt)
-#pragma unroll
-      for (int m = 0; m < MT; ++m) {
-        const bf16x8 b = *reinterpret_cast<const bf16x8*>(cur + (m * KPI + kt) * 1024 + lane * 16);
-#pragma unroll
-        for (int n = 0; n < NTW; ++n)
-          acc[n][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[n][kt], b, acc[n][m], 0, 0, 0);
-      }
-  };
-
-  // Two iterations per trip so both register sets are indexed statically.
-  for (int it = 0; it < iters; it += 2) {
-    if (it + 1 < iters) {
-      stage_x(smem + STAGE, kt_begin + (it + 1) * KPI);
-      load_w(wb, kt_begin + (it + 1) * KPI);
-    }
-    compute(smem, wa);
-    __syncthreads();
-    if (it + 1 < iters) {
-      if (it + 2 < iters) {
-        stage_x(smem, kt_begin + (it + 2) * KPI);
-        load_w(wa, kt_begin + (it + 2) * KPI);
-      }
-      compute(smem + STAGE, wb);
-      __syncthreads();
-    }
-  }
-
-  const size_t slab = (EPI == EPI_F32) ? static_cast<size_t>(blockIdx.y) * M * ldy : 0;
-#pragma unroll
-  for (int n = 0; n < NTW; ++n)
-#pragma unroll
-    for (int m = 0; m < MT; ++m) {
-      if constexpr (EPI == EPI_SWIGLU) {
-        if (n & 1) continue;
-        store_tile<EPI>(acc[n][m], &acc[(n + 1) % NTW][m], Y, bias, m * 16, (nt0 + n) * 16, M, N, ldy, lane, 0);
-      } else {
-        store_tile<EPI>(acc[n][m], nullptr, Y, gridDim.y > 1 ? nullptr : bias, m * 16, (nt0 + n) * 16, M, N,
-                        ldy, lane, slab);
-      }
-    }
-}
-
 // Sums S fp32 slabs [S, M, N] (+bias) and writes bf16 (mode 0), fp32 (mode 1) or
 // SwiGLU over gate/up n-tiles interleaved at 16 columns (mode 2, out [M, N/2]).
 __global__ void splitk_reduce_kernel(const float* __restrict__ part, const bf16_t* __restrict__ bias,
@@ -347,23 +244,6 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ part, const bf16_
   }
 }
 
-template <int MT, int NTW, int KPI>
-int launch_ws(int epi, const bf16_t* Wp, const bf16_t* X, void* Y, const bf16_t* bias, int M, int N,
-              int K, int ldy, int n_pad, int splits, hipStream_t stream) {
-  const dim3 grid(n_pad / (64 * NTW), splits), block(256);
-  const size_t lds = 2 * MT * KPI * 1024;
-  const int ktps = (K / 32) / splits;
-  if (epi == EPI_BF16)
-    wsgemm_kernel<MT, NTW, KPI, EPI_BF16><<<grid, block, lds, stream>>>(Wp, X, Y, bias, M, N, K, ldy, ktps);
-  else if (epi == EPI_F32)
-    wsgemm_kernel<MT, NTW, KPI, EPI_F32><<<grid, block, lds, stream>>>(Wp, X, Y, bias, M, N, K, ldy, ktps);
-  else if constexpr (NTW >= 2)
-    wsgemm_kernel<MT, NTW, KPI, EPI_SWIGLU><<<grid, block, lds, stream>>>(Wp, X, Y, bias, M, N, K, ldy, ktps);
-  else
-    return -3;
-  return static_cast<int>(hipGetLastError());
-}
-
 }  // namespace
 
 // Y = X * W^T with a 128x128 tile. Requirements: K % 64 == 0, n_pad % 128 == 0 (the
@@ -387,37 +267,6 @@ LC_EXPORT int lc_gemm_tile(const void* Wp, const void* X, void* Y, const void* b
   else
     return -2;
   LC_RETURN_LAST_ERROR();
-}
-
-// Weight-streaming GEMM for M <= 256. `splits` > 1 requires epi == EPI_F32 and Y = fp32
-// workspace of [splits, M, ldy]; follow with lc_splitk_reduce. (K/32) % splits == 0.
-LC_EXPORT int lc_wsgemm(const void* Wp, const void* X, void* Y, const void* bias, int M, int N, int K,
-                        int n_pad, int ldy, int epi, int splits, hipStream_t stream) {
-  if (M <= 0) return 0;
-  if (M > 256 || K % 32 || n_pad % 128 || N > n_pad || splits < 1) return -1;
-  if (splits > 1 && epi != EPI_F32) return -1;
-  auto w = static_cast<const bf16_t*>(Wp);
-  auto x = static_cast<const bf16_t*>(X);
-  auto b = static_cast<const bf16_t*>(bias);
-  const int kt = K / 32;
-  const int mt = (M + 15) / 16;
-  // KPI (k-tiles per iteration) shrinks as M grows so one X stage stays <= 32 KiB.
-  if (mt <= 1) {
-    if (kt % splits) return -1;
-    return launch_ws<1, 2, 8>(epi, w, x, Y, b, M, N, K, ldy, n_pad, splits, stream);
-  } else if (mt <= 2) {
-    if (kt % splits) return -1;
-    return launch_ws<2, 2, 8>(epi, w, x, Y, b, M, N, K, ldy, n_pad, splits, stream);
-  } else if (mt <= 4) {
-    if (kt % splits) return -1;
-    return launch_ws<4, 2, 8>(epi, w, x, Y, b, M, N, K, ldy, n_pad, splits, stream);
-  } else if (mt <= 8) {
-    if (kt % splits) return -1;
-    return launch_ws<8, 2, 4>(epi, w, x, Y, b, M, N, K, ldy, n_pad, splits, stream);
-  } else {
-    if (kt % splits) return -1;
-    return launch_ws<16, 2, 2>(epi, w, x, Y, b, M, N, K, ldy, n_pad, splits, stream);
-  }
 }
 
 LC_EXPORT int lc_splitk_reduce(const void* part, const void* bias, void* Y, int S, int M, int N, int ldy,

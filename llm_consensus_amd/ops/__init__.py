@@ -17,16 +17,14 @@ from . import reference as ref
 
 EPI_BF16, EPI_F32, EPI_SWIGLU = 0, 1, 2
 
-# M at or below which the weight-streaming kernel is used instead of the 128x128 tile kernel.
+# M at or below which the decode kernels (one activation panel) are used instead of the tile kernels.
 WS_MAX_M = int(os.environ.get("LC_WS_MAX_M", "256"))
 # Fewest 256x256 tiles for which the 256x256 pipelined kernel is used. It beats the 128x128 kernel
 # even when its tiles cover a third of the CUs (160 tiles: 171 vs 308 us, 80 tiles: 145 vs 155 us at
 # K = 8192), and below half coverage its split-K form takes over, so the default is "always".
 # -1 disables the kernel (128x128 tiles everywhere).
 GEMM256_MIN_TILES = int(os.environ.get("LC_GEMM256_MIN_TILES", "1"))
-# Decode GEMM for 17..256 rows: "panel" (gemm_panel.hip, deep LDS-DMA ring) or "ws" (weight-streaming
-# wsgemm in gemm.hip, kept for comparison), and the panel kernel's split-K policy.
-DECODE_KERNEL = os.environ.get("LC_DECODE_KERNEL", "panel")
+# Decode GEMM for 9..256 rows: the panel kernel (gemm_panel.hip, deep LDS-DMA ring) and its split-K policy.
 PANEL_MAX_BLOCKS = int(os.environ.get("LC_PANEL_MAX_BLOCKS", "256"))
 PANEL_MIN_KTILES = int(os.environ.get("LC_PANEL_MIN_KTILES", "4"))
 # Ring depth of the panel kernel for M <= 128: deep (all of a CU's LDS, one workgroup per CU, fastest
@@ -58,8 +56,6 @@ KGEMM_MAX_M = int(os.environ.get("LC_KGEMM_MAX_M", "8"))
 KGEMM_LONG_K = 8192          # beyond this K the kernel is only used up to KGEMM_LONG_K_MAX_M rows
 KGEMM_LONG_K_MAX_M = 4
 KGEMM_FORCE_NTW = int(os.environ.get("LC_KGEMM_NTW", "-1"))
-# Target number of workgroups for the weight-streaming kernel (256 CUs on MI355X).
-WS_TARGET_BLOCKS = int(os.environ.get("LC_WS_TARGET_BLOCKS", "256"))
 
 
 def _hip():
@@ -152,21 +148,6 @@ def _kgemm_ntw(n_pad: int, M: int, swiglu: bool, K: int = 0) -> int:
     return 2 if swiglu else 1
 
 
-def _choose_splits(n_pad: int, K: int, M: int, allow: bool) -> int:
-    if not allow:
-        return 1
-    blocks = n_pad // 128
-    kt = K // 32
-    kpi = 8 if M <= 64 else (4 if M <= 128 else 2)
-    best = 1
-    for s in (2, 3, 4, 6, 8, 12, 16):
-        if blocks * best >= WS_TARGET_BLOCKS:
-            break
-        if kt % s == 0 and kt // s >= 2 * kpi:
-            best = s
-    return best
-
-
 def _choose_panel_splits(n_pad: int, K: int) -> int:
     """K splits of the panel kernel (gemm_panel.hip). Its LDS ring admits one workgroup per CU,
     so the aim is as many workgroups as possible WITHOUT exceeding the 256 CUs (a 257th would
@@ -225,7 +206,7 @@ def use_wide_panel(M: int, n_pad: int, k: int) -> bool:
     """Whether a decode GEMM of ``M`` rows against ``n_pad`` columns takes the 160-column workgroups:
     its 128-column tiles would need a second round on the 256 CUs (and K is not split), while
     ten-n-tile workgroups cover it in one."""
-    return (PANEL_WIDE and DECODE_KERNEL == "panel" and M <= PANEL_WIDE_MAX_M and n_pad // 128 > 256
+    return (PANEL_WIDE and M <= PANEL_WIDE_MAX_M and n_pad // 128 > 256
             and (n_pad // 16 + 9) // 10 <= 256 and _choose_panel_splits(n_pad, k) == 1)
 
 
@@ -285,12 +266,9 @@ def linear(x: torch.Tensor, w: LinearWeight, out_f32: bool = False, defer_reduce
         h.call("lc_gemm256", w.data.data_ptr(), x.data_ptr(), y.data_ptr(), h.ptr(w.bias), M, w.n, w.k, w.n_pad,
                out_n, epi)
         return y
-    if DECODE_KERNEL == "panel":
-        kernel, splits, extra = "lc_gemm_panel", _choose_panel_splits(w.n_pad, w.k), (1 if PANEL_DEEP else 0,)
-        if wide:
-            extra = (2,)
-    else:
-        kernel, splits, extra = "lc_wsgemm", _choose_splits(w.n_pad, w.k, M, allow=True), ()
+    kernel, splits, extra = "lc_gemm_panel", _choose_panel_splits(w.n_pad, w.k), (1 if PANEL_DEEP else 0,)
+    if wide:
+        extra = (2,)
     if splits == 1:
         h.call(kernel, w.data.data_ptr(), x.data_ptr(), y.data_ptr(), h.ptr(w.bias), M, w.n, w.k, w.n_pad, out_n, epi, 1,
                *extra)
@@ -338,25 +316,6 @@ def rmsnorm(hstate: torch.Tensor, w: torch.Tensor, eps: float, delta=None) -> to
                delta.part.data_ptr(), delta.part.shape[0])
     else:
         h.call("lc_rmsnorm", hstate.data_ptr(), h.ptr(delta), w.data_ptr(), y.data_ptr(), T, d, float(eps), None, 0)
-    return y
-
-
-def swiglu(gu: torch.Tensor) -> torch.Tensor:
-    if not gu.is_cuda:
-        return ref.swiglu(gu)
-    h = _hip()
-    T, two = gu.shape
-    act = torch.empty(T, two // 2, dtype=gu.dtype, device=gu.device)
-    h.call("lc_swiglu", gu.data_ptr(), act.data_ptr(), T, two // 2)
-    return act
-
-
-def add(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
-    if not a.is_cuda:
-        return (a.float() + b.float()).to(a.dtype)
-    h = _hip()
-    y = torch.empty_like(a)
-    h.call("lc_add", a.data_ptr(), b.data_ptr(), y.data_ptr(), a.numel())
     return y
 
 

@@ -21,15 +21,12 @@ _P, _I, _F, _L = c_void_p, c_int, c_float, c_longlong
 _SIGNATURES = {
     "lc_embed_gather": [_P, _P, _P, _I, _I, _I, _P, _P, _P],
     "lc_rmsnorm": [_P, _P, _P, _P, _I, _I, _F, _P, _I, _P],
-    "lc_swiglu": [_P, _P, _I, _I, _P],
-    "lc_add": [_P, _P, _P, _L, _P],
     "lc_copy_blocks": [_P, _P, _P, _I, _L, _L, _I, _P],
     "lc_embed_pool": [_P, _P, _P, _P, _I, _I, _I, _P],
     "lc_l2_normalize": [_P, _P, _I, _I, _P],
     "lc_gemm_tile": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "lc_gemm256": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "lc_gemm_panel": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P],
-    "lc_wsgemm": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
     "lc_kgemm": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
     "lc_splitk_reduce": [_P, _P, _P, _I, _I, _I, _I, _I, _P],
     "lc_gemm_grouped": [_P, _L, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _P],

@@ -9,8 +9,7 @@ replicas.
 """
 from __future__ import annotations
 
-from dataclasses import dataclass
-from typing import Dict, List
+from typing import List
 
 from .._native import core
 from ..models.config import from_hf_config, get_preset
@@ -37,27 +36,3 @@ def plan_for_config(cfg, num_gpus: int, hbm_bytes: int = HBM_BYTES_MI355X,
                     reserve_fraction: float = 0.08) -> "core.PlacementPlan":
     policy = core.PlacementPolicy.Spread if cfg.placement == "spread" else core.PlacementPolicy.Pack
     return core.plan_placement(member_specs(cfg), max(1, num_gpus), hbm_bytes, reserve_fraction, policy)
-
-
-@dataclass
-class RankAssignment:
-    replica: int                   # index of the replica this rank belongs to (-1: idle)
-    num_replicas: int
-    local_index: int               # position of this rank inside its replica
-    replica_ranks: List[int]       # ranks of the replica (for its process group)
-    models: Dict[str, List[int]]   # model key -> ranks of its TP/EP group, for models this rank hosts
-
-
-def assignment_for_rank(plan: "core.PlacementPlan", cfg, rank: int) -> RankAssignment:
-    """What one process (rank == node-local GPU id) has to load under ``plan``."""
-    for ri, rep in enumerate(plan.replicas):
-        devs = list(rep.devices)
-        if rank not in devs:
-            continue
-        models: Dict[str, List[int]] = {}
-        by_name = {m.name: m for m in cfg.members}
-        for mp in rep.members:
-            if rank in mp.devices:
-                models.setdefault(cfg.models[by_name[mp.name].model].name, list(mp.devices))
-        return RankAssignment(ri, len(plan.replicas), devs.index(rank), devs, models)
-    return RankAssignment(-1, len(plan.replicas), 0, [], {})

@@ -15,7 +15,7 @@ from llm_consensus_amd import cli
 from llm_consensus_amd.app import build_ensemble
 from llm_consensus_amd.config import ConsensusConfig, load_config
 from llm_consensus_amd.consensus.backend import ScriptedBackend
-from llm_consensus_amd.parallel.placement import assignment_for_rank, plan_for_config
+from llm_consensus_amd.parallel.placement import plan_for_config
 from llm_consensus_amd.serve.server import ConsensusServer
 
 CONFIGS = Path(__file__).resolve().parent.parent / "configs"
@@ -235,8 +235,9 @@ def test_placement_three_small_models_pack_to_one_gpu_and_replicate():
     cfg = load_config(str(CONFIGS / "ensemble_3x8b.toml"))
     plan = plan_for_config(cfg, 8)
     assert plan.feasible and plan.gpus_per_replica == 1 and len(plan.replicas) == 8
-    a = assignment_for_rank(plan, cfg, 5)
-    assert a.replica == 5 and a.num_replicas == 8 and sorted(a.models) == ["llama", "mistral", "qwen"]
+    rep = plan.replicas[5]
+    assert list(rep.devices) == [5] and sorted({cfg.models[m.model].name for m in cfg.members}) == ["llama", "mistral", "qwen"]
+    assert all(list(m.devices) == [5] for m in rep.members)
 
 
 def test_placement_70b_judge_spread():
@@ -247,8 +248,8 @@ def test_placement_70b_judge_spread():
     judge = next(m for m in rep.members if m.name == "judge")
     assert len(judge.devices) == 4 and plan.gpus_per_replica == 8      # 4 proposers on a GPU each + TP=4 judge
     assert len({d for m in rep.members for d in m.devices}) == 8
-    for r in judge.devices:
-        assert assignment_for_rank(plan, cfg, r).models["judge"] == list(judge.devices)
+    proposer_gpus = [d for m in rep.members if m.name != "judge" for d in m.devices]
+    assert len(proposer_gpus) == 4 and not set(proposer_gpus) & set(judge.devices)
 
 
 def test_placement_infeasible_reports_error():
