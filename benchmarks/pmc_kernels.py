@@ -51,6 +51,19 @@ def run():
     qkv = rnd(64, (Hq + 2 * Hkv) * Dh, scale=0.5)
     for _ in range(3):
         ops.attn_decode(qkv, kc, vt, bt, ctx, Hq, Hkv, Dh, Dh ** -0.5, 0, 4)
+    # ---- self-consistency step: 16 prompts x 16 chains, 512 shared prompt tokens + private suffix
+    bt_sc = torch.empty(256, 10, dtype=torch.int32, device=dev)
+    rows = torch.arange(256, device=dev)
+    bt_sc[:, :8] = ((rows // 16) * 8).view(-1, 1).int() + torch.arange(8, device=dev, dtype=torch.int32)
+    bt_sc[:, 8] = (128 + rows).int()
+    bt_sc[:, 9] = 0
+    ctx_sc = torch.full((256,), 544, dtype=torch.int32, device=dev)
+    begin_sc = torch.full((256,), 512, dtype=torch.int32, device=dev)
+    groups = (torch.arange(0, 256, 16, dtype=torch.int32, device=dev), torch.full((16,), 16, dtype=torch.int32, device=dev),
+              torch.full((16,), 8, dtype=torch.int32, device=dev))
+    qkv_sc = rnd(256, (Hq + 2 * Hkv) * Dh, scale=0.5)
+    for _ in range(3):
+        ops.attn_decode(qkv_sc, kc, vt, bt_sc, ctx_sc, Hq, Hkv, Dh, Dh ** -0.5, 0, 1, groups, begin_sc, 16, 4)
     T = 16 * 512
     qkv_p = rnd(T, (Hq + 2 * Hkv) * Dh, scale=0.5)
     cu = torch.arange(0, T + 1, 512, dtype=torch.int32, device=dev)

@@ -143,10 +143,18 @@ def build_ensemble(cfg: ConsensusConfig, device: Optional[torch.device] = None,
     backends = dict(backends or {})
     used_models = {m.model for m in cfg.members}
     if device.type == "cuda":
-        plan = plan_for_config(cfg, torch.cuda.device_count())
-        if not plan.feasible:
-            raise RuntimeError(f"placement failed: {plan.error}")
+        # this process holds every model whole on ONE device: that is what has to fit
+        packed = plan_for_config(cfg, 1, single_process=True)
+        if not packed.feasible:
+            raise RuntimeError(f"placement failed: {packed.error}")
+        want = max([max(m.tp, m.ep) for m in cfg.models.values()] + [1])
+        plan = plan_for_config(cfg, max(torch.cuda.device_count(), want))
         log.debug("placement: %d GPU(s) per replica, %d replica(s)", plan.gpus_per_replica, len(plan.replicas))
+        if plan.feasible and plan.gpus_per_replica > 1:
+            # one process hosts every model on ONE device whatever the plan says: say so (the front
+            # ends start one rank per planned GPU themselves, parallel/launch.py)
+            log.warning("this ensemble is planned for %d GPUs per replica but is being built in one process: every "
+                        "model goes to %s and tp / ep settings are ignored", plan.gpus_per_replica, device)
     for name in used_models:
         if name not in backends:
             backends[name] = build_backend(cfg.models[name], device)

@@ -716,7 +716,10 @@ def init_distributed(device_type: Optional[str] = None):
     """Process-group bring-up from the launcher's environment (RANK / LOCAL_RANK / WORLD_SIZE /
     MASTER_*): RCCL ("nccl") with one GPU per process when GPUs are present, gloo otherwise.
     The collective timeout is a day: a front end's ranks wait in a collective while rank 0 waits
-    for the next question. Returns (comm, device)."""
+    for the next question. LC_SHARE_GPU=1 is the rehearsal mode of a one-GPU machine: every rank
+    uses GPU 0, the process group is gloo with host-staged tensors (RCCL refuses two ranks on one
+    device) and model groups still use the peer-to-peer kernels over IPC-mapped memory.
+    Returns (comm, device)."""
     import os
     from datetime import timedelta
 
@@ -726,7 +729,11 @@ def init_distributed(device_type: Optional[str] = None):
 
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     use_gpu = (device_type or ("cuda" if torch.cuda.is_available() else "cpu")) == "cuda"
-    if use_gpu:
+    if use_gpu and os.environ.get("LC_SHARE_GPU", "0") == "1":
+        torch.cuda.set_device(0)
+        device = torch.device("cuda", 0)
+        dist.init_process_group("gloo", timeout=timedelta(hours=24))
+    elif use_gpu:
         local = int(os.environ.get("LOCAL_RANK", "0"))
         torch.cuda.set_device(local)
         device = torch.device("cuda", local)

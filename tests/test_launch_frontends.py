@@ -133,3 +133,66 @@ def test_http_server_starts_its_own_ranks(spread_cfg, gpus):
             proc.wait(30)
         except subprocess.TimeoutExpired:
             proc.kill()
+
+
+JUDGE_TP2 = """
+strategy = "judge_logprob"
+[sampling]
+temperature = 0.0
+max_new_tokens = 6
+[models.p]
+preset = "tiny-llama"
+seed = 1
+kv_blocks = 512
+[models.q]
+preset = "tiny-qwen"
+seed = 3
+kv_blocks = 512
+[models.judge]
+preset = "small-llama"
+seed = 2
+kv_blocks = 512
+tp = 2
+[[members]]
+name = "p0"
+model = "p"
+[[members]]
+name = "p1"
+model = "q"
+[[members]]
+name = "judge"
+model = "judge"
+role = "judge"
+"""
+
+
+@pytest.mark.gpu
+def test_repl_with_two_ranks_and_a_tensor_parallel_judge_on_one_gpu(tmp_path):
+    """The plain command on the real kernels: `llm-consensus --gpus 2` starts two ranks (rehearsal
+    mode: both on GPU 0), the judge is a TP=2 group over the peer-to-peer kernels, the start-up
+    warm-up records its decode graphs on both ranks, and the questions are served in lock-step
+    rounds. The judge's scores agree with those of one process holding the unsharded judge up to
+    the reduction order of bf16 partial sums, and a clear decision is the same decision."""
+    cfg = tmp_path / "judge.toml"
+    cfg.write_text(JUDGE_TP2)
+
+    def run(gpus, extra_env):
+        e = env()
+        e.update(HSA_ENABLE_IPC_MODE_LEGACY="0", LC_P2P_GRID_CAP="32", **extra_env)
+        p = subprocess.run([sys.executable, "-m", "llm_consensus_amd.cli", "--config", str(cfg), "--gpus", str(gpus),
+                            "--json"], input="\n".join(QUESTIONS) + "\nexit\n", capture_output=True, text=True, env=e,
+                           timeout=400)
+        assert p.returncode == 0, p.stderr[-3000:]
+        recs = [json.loads(l[l.index("{"):]) for l in p.stdout.splitlines() if "{" in l]
+        return recs
+
+    two = run(2, {"LC_SHARE_GPU": "1"})
+    assert [r["question"] for r in two] == QUESTIONS and all(r["strategy"] == "judge_logprob" for r in two)
+    one = run(1, {})
+    for a, b in zip(two, one):
+        assert [v["candidate"] for v in a["votes"]] == [v["candidate"] for v in b["votes"]] == ["p0", "p1"]
+        sa = [sum(v["scores"]) for v in a["votes"]]
+        sb = [sum(v["scores"]) for v in b["votes"]]
+        assert all(abs(x - y) < 0.35 + 0.02 * abs(y) for x, y in zip(sa, sb)), (sa, sb)
+        if abs(sb[0] - sb[1]) > 1.0:              # a clear decision survives the sharded reduction order
+            assert a["answer"] == b["answer"]
