@@ -392,7 +392,7 @@ LC_DEVICE void decode_one_wave(const bf16_t* __restrict__ Q, int q_stride, const
                                const int32_t* __restrict__ kv_begin, bf16_t* __restrict__ out,
                                float* __restrict__ part_o, float* __restrict__ part_lse, int np_total, int Hq,
                                int Hkv, int lbs, float scale2, int window, int kvh, int b, int split, int nsplit,
-                               int lane) {
+                               int lane, bool merge_prefix) {
   const int G = Hq / Hkv;
   const int q = lane & 31;
   const bool valid = q < G;
@@ -411,6 +411,65 @@ LC_DEVICE void decode_one_wave(const bf16_t* __restrict__ Q, int q_stride, const
   TileCtx c{Kc, Vt, block_tables + static_cast<size_t>(b) * max_blocks, Hkv, kvh, lbs, 1 << lbs, scale2};
   AttnState<DH> st;
   init_state<DH>(st);
+  if (merge_prefix) {
+    // nsplit == 1 and the shared-prefix pass has ALREADY run: this wave holds the row's whole
+    // private range, so it folds the prefix partials (slots 1 .. np_total-1: normalised fp32 rows
+    // + log-sum-exp) into its own state and writes the final bf16 row: no partial slot for the
+    // private range, no merge launch. The first prefix slot is requested before the private
+    // keys are walked, so its round trip overlaps theirs.
+    const int h = lane >> 5;
+    const bool has_prefix = valid && begin > 0 && (!kv_begin || kv_begin[b] > 0);
+    const size_t slot = (static_cast<size_t>(b) * Hq + (valid ? head : 0)) * np_total;
+    f32x4 pre[DH / 32][4];
+    float pre_lse = kNegBig;
+    if (has_prefix) {
+      pre_lse = part_lse[slot + 1];
+#pragma unroll
+      for (int blk = 0; blk < DH / 32; ++blk)
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4)
+          pre[blk][g4] = *reinterpret_cast<const f32x4*>(part_o + (slot + 1) * DH + blk * 32 + 8 * g4 + 4 * h);
+    } else {
+#pragma unroll
+      for (int blk = 0; blk < DH / 32; ++blk)
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) pre[blk][g4] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    if (lo < hi) attend_range<DH>(st, qf, c, lo, hi, valid ? lo : 0, valid ? hi : 0, lane);
+    const float l_all = st.l + __shfl_xor(st.l, 32, 64);
+    float mx = fmaxf(st.m, pre_lse);
+    if (has_prefix)
+      for (int p = 2; p < np_total; ++p) mx = fmaxf(mx, part_lse[slot + p]);
+    const float a0 = fast_exp2(st.m - mx);
+    const float w1 = pre_lse > 0.5f * kNegBig ? fast_exp2(pre_lse - mx) : 0.f;
+    float den = l_all * a0 + w1;
+#pragma unroll
+    for (int blk = 0; blk < DH / 32; ++blk)
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4)
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4) st.o[blk][4 * g4 + r4] = st.o[blk][4 * g4 + r4] * a0 + w1 * pre[blk][g4][r4];
+    if (has_prefix)
+      for (int p = 2; p < np_total; ++p) {
+        const float lp = part_lse[slot + p];
+        if (lp <= 0.5f * kNegBig) continue;
+        const float w = fast_exp2(lp - mx);
+        den += w;
+#pragma unroll
+        for (int blk = 0; blk < DH / 32; ++blk)
+#pragma unroll
+          for (int g4 = 0; g4 < 4; ++g4) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(part_o + (slot + p) * DH + blk * 32 + 8 * g4 + 4 * h);
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) st.o[blk][4 * g4 + r4] += w * v[r4];
+          }
+      }
+    // finish_and_store divides by the sum over both lane halves of st.l
+    st.l = 0.5f * den;
+    finish_and_store<DH>(st, valid ? out + static_cast<size_t>(b) * (Hq * DH) + head * DH : nullptr, nullptr,
+                         nullptr, lane);
+    return;
+  }
   if (lo < hi) attend_range<DH>(st, qf, c, lo, hi, valid ? lo : 0, valid ? hi : 0, lane);
   if (part_o) {
     const size_t slot = (static_cast<size_t>(b) * Hq + head) * np_total + split;
@@ -433,10 +492,10 @@ __global__ __launch_bounds__(64) void attn_decode_kernel(const bf16_t* __restric
                                    const int32_t* __restrict__ ctx_lens, const int32_t* __restrict__ kv_begin,
                                    bf16_t* __restrict__ out, float* __restrict__ part_o,
                                    float* __restrict__ part_lse, int np_total, int Hq, int Hkv, int lbs,
-                                   float scale2, int window) {
+                                   float scale2, int window, int merge_prefix) {
   decode_one_wave<DH>(Q, q_stride, Kc, Vt, block_tables, max_blocks, ctx_lens, kv_begin, out, part_o, part_lse,
                       np_total, Hq, Hkv, lbs, scale2, window, blockIdx.x, blockIdx.y, blockIdx.z, gridDim.z,
-                      threadIdx.x & 63);
+                      threadIdx.x & 63, merge_prefix != 0);
 }
 
 // Multi-wave variant: the block's key range is cut into NW sub-ranges, one per wave, and the
@@ -727,8 +786,11 @@ LC_EXPORT int lc_attn_decode(const void* Q, int q_stride, const void* Kc, const 
                              const void* block_tables, int max_blocks, const void* ctx_lens,
                              const void* kv_begin, void* out, void* part_o, void* part_lse, int np_total,
                              int nsplit, int n_seqs, int Hq, int Hkv, int Dh, int block_size, float scale,
-                             int window, int waves, hipStream_t stream) {
+                             int window, int waves, int merge_prefix, hipStream_t stream) {
   if (n_seqs <= 0) return 0;
+  // merge_prefix: the shared-prefix pass has run; one wave per (row, kv head) walks the private keys,
+  // folds the prefix slots 1 .. np_total-1 in and writes the final rows
+  if (merge_prefix && (waves != 1 || nsplit != 1 || !part_o || !part_lse || !kv_begin || np_total < 2)) return -1;
   if (Hq % Hkv || Hq / Hkv > 32 || (Dh != 64 && Dh != 128) || block_size % 8 ||
       (block_size & (block_size - 1)) || nsplit < 1 || (!part_o && nsplit != 1) || nsplit > np_total)
     return -1;
@@ -748,9 +810,9 @@ LC_EXPORT int lc_attn_decode(const void* Q, int q_stride, const void* Kc, const 
     if (Dh == 128) attn_decode_mw_kernel<128, 2><<<grid, dim3(128), 0, stream>>>(LC_ARGS);
     else attn_decode_mw_kernel<64, 2><<<grid, dim3(128), 0, stream>>>(LC_ARGS);
   } else if (Dh == 128) {
-    attn_decode_kernel<128><<<grid, block, 0, stream>>>(LC_ARGS);
+    attn_decode_kernel<128><<<grid, block, 0, stream>>>(LC_ARGS, merge_prefix);
   } else {
-    attn_decode_kernel<64><<<grid, block, 0, stream>>>(LC_ARGS);
+    attn_decode_kernel<64><<<grid, block, 0, stream>>>(LC_ARGS, merge_prefix);
   }
 #undef LC_ARGS
   LC_RETURN_LAST_ERROR();

@@ -409,6 +409,9 @@ MOE_PANEL_MAX_ROWS = int(os.environ.get("LC_MOE_PANEL_ROWS", "640"))   # routed 
 MOE_GEMM256_MIN_ROWS = int(os.environ.get("LC_MOE_G256_ROWS", "641"))   # routed rows from which the 256x256 grouped GEMM is used
 GEMM256_MAX_SPLITS = int(os.environ.get("LC_G256_SPLITS", "8"))
 ATTN_PREFIX_WAVES = 4   # 1 = one wave per prefix piece and one partial slot per piece
+# The per-row pass folds the shared-prefix partials in and writes the final rows (LC_ATTN_FOLD_PREFIX=0:
+# the three-launch form with a separate merge, kept for comparison runs).
+ATTN_FOLD_PREFIX = os.environ.get("LC_ATTN_FOLD_PREFIX", "1") == "1"
 
 
 def choose_kv_splits(B: int, Hkv: int, max_ctx: int) -> int:
@@ -448,7 +451,7 @@ def attn_decode(qkv, k_cache, vt_cache, block_tables, ctx_lens, Hq, Hkv, Dh, sca
     if nsplit == 1 and not use_prefix:
         h.call("lc_attn_decode", qkv.data_ptr(), qkv.stride(0), k_cache.data_ptr(), vt_cache.data_ptr(),
                block_tables.data_ptr(), block_tables.shape[1], ctx_lens.data_ptr(), None, out.data_ptr(), None, None,
-               1, 1, B, Hq, Hkv, Dh, k_cache.shape[2], float(scale), int(window), waves)
+               1, 1, B, Hq, Hkv, Dh, k_cache.shape[2], float(scale), int(window), waves, 0)
         return out
     # The prefix pass merges four pieces of its key range on chip the same way.
     pwaves = 4 if (use_prefix and prefix_splits >= 4 and ATTN_PREFIX_WAVES >= 4) else 1
@@ -456,10 +459,24 @@ def attn_decode(qkv, k_cache, vt_cache, block_tables, ctx_lens, Hq, Hkv, Dh, sca
     np_total = nsplit + (prefix_splits if use_prefix else 0)
     part_o = torch.empty(B, Hq, np_total, Dh, dtype=torch.float32, device=qkv.device)
     part_lse = torch.empty(B, Hq, np_total, dtype=torch.float32, device=qkv.device)
+    # With one private split per row the per-row pass runs AFTER the shared-prefix pass and folds
+    # the prefix slots into its own result: two launches and no partial slot for the private range
+    # (16 x 16-chain step of Llama-3-8B: 7.70 -> 7.61 ms; both passes as one launch of independent
+    # workgroups + merge measured 7.72: they do not overlap, the per-row pass is bound by its ~30 MB of private keys).
+    fold = use_prefix and nsplit == 1 and waves == 1 and kv_begin is not None and ATTN_FOLD_PREFIX
+    if use_prefix and fold:
+        gf, gc, gs = groups
+        h.call("lc_attn_prefix", qkv.data_ptr(), qkv.stride(0), k_cache.data_ptr(), vt_cache.data_ptr(),
+               block_tables.data_ptr(), block_tables.shape[1], gf.data_ptr(), gc.data_ptr(), gs.data_ptr(),
+               gf.numel(), int(max_group_rows), int(prefix_splits), part_o.data_ptr(), part_lse.data_ptr(), np_total,
+               nsplit, Hq, Hkv, Dh, k_cache.shape[2], float(scale), pwaves)
     h.call("lc_attn_decode", qkv.data_ptr(), qkv.stride(0), k_cache.data_ptr(), vt_cache.data_ptr(),
            block_tables.data_ptr(), block_tables.shape[1], ctx_lens.data_ptr(),
            kv_begin.data_ptr() if (use_prefix and kv_begin is not None) else None, out.data_ptr(), part_o.data_ptr(),
-           part_lse.data_ptr(), np_total, nsplit, B, Hq, Hkv, Dh, k_cache.shape[2], float(scale), int(window), waves)
+           part_lse.data_ptr(), np_total, nsplit, B, Hq, Hkv, Dh, k_cache.shape[2], float(scale), int(window), waves,
+           1 if fold else 0)
+    if fold:
+        return out
     if use_prefix:
         gf, gc, gs = groups
         h.call("lc_attn_prefix", qkv.data_ptr(), qkv.stride(0), k_cache.data_ptr(), vt_cache.data_ptr(),

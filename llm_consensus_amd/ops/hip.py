@@ -35,7 +35,7 @@ _SIGNATURES = {
     "lc_gemm_panel_grouped": [_P, _L, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _P],
     "lc_rope_kv_write": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _I, _P, _P],
     "lc_attn_prefill": [_P, _I, _P, _P, _P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _F, _I, _P],
-    "lc_attn_decode": [_P, _I, _P, _P, _P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _F, _I, _I, _P],
+    "lc_attn_decode": [_P, _I, _P, _P, _P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _F, _I, _I, _I, _P],
     "lc_attn_prefix": [_P, _I, _P, _P, _P, _I, _P, _P, _P, _I, _I, _I, _P, _P, _I, _I, _I, _I, _I, _I, _F, _I, _P],
     "lc_attn_merge": [_P, _P, _P, _I, _I, _I, _P],
     "lc_fill_f32": [_P, _F, _L, _P],
