@@ -24,6 +24,9 @@ WS_MAX_M = int(os.environ.get("LC_WS_MAX_M", "256"))
 # K = 8192), and below half coverage its split-K form takes over, so the default is "always".
 # -1 disables the kernel (128x128 tiles everywhere).
 GEMM256_MIN_TILES = int(os.environ.get("LC_GEMM256_MIN_TILES", "1"))
+# Reduction depth from which prefill-sized GEMMs take the four-wave 256 x 256 kernel (gemm256w.hip):
+# its longer prologue pays off only over many K-tiles (0 = never).
+GEMM256W_MIN_K = int(os.environ.get("LC_GEMM256W_MIN_K", "8192")) or (1 << 30)
 # Decode GEMM for 9..256 rows: the panel kernel (gemm_panel.hip, deep LDS-DMA ring) and its split-K policy.
 PANEL_MAX_BLOCKS = int(os.environ.get("LC_PANEL_MAX_BLOCKS", "256"))
 PANEL_MIN_KTILES = int(os.environ.get("LC_PANEL_MIN_KTILES", "4"))
@@ -202,6 +205,14 @@ class PartialSum:
         return y
 
 
+def use_four_wave_gemm(k: int, out_f32: bool = False) -> bool:
+    """Whether a prefill-sized GEMM (256 x 256 tiles) of reduction depth ``k`` takes the four-wave
+    kernel (gemm256w.hip) instead of the eight-wave one: from GEMM256W_MIN_K on (the down
+    projections of the served models: K = 14336 / 18944 / 28672; QKV, O and gate/up have K = d_model).
+    The four-wave kernel has bf16 and SwiGLU epilogues only and needs at least four K-tiles."""
+    return not out_f32 and k >= max(GEMM256W_MIN_K, 256)
+
+
 def use_wide_panel(M: int, n_pad: int, k: int) -> bool:
     """Whether a decode GEMM of ``M`` rows against ``n_pad`` columns takes the 160-column workgroups:
     its 128-column tiles would need a second round on the 256 CUs (and K is not split), while
@@ -244,7 +255,9 @@ def linear(x: torch.Tensor, w: LinearWeight, out_f32: bool = False, defer_reduce
                    1 if out_f32 else 0)
             return y
         if GEMM256_MIN_TILES >= 0 and w.n_pad % 256 == 0 and tiles256 >= GEMM256_MIN_TILES:
-            h.call("lc_gemm256", w.data.data_ptr(), x.data_ptr(), y.data_ptr(), h.ptr(w.bias), M, w.n, w.k, w.n_pad,
+            # long K (down projections): four waves of 128 x 128 with the accumulators in AGPRs
+            kern = "lc_gemm256w" if use_four_wave_gemm(w.k, epi == EPI_F32) else "lc_gemm256"
+            h.call(kern, w.data.data_ptr(), x.data_ptr(), y.data_ptr(), h.ptr(w.bias), M, w.n, w.k, w.n_pad,
                    out_n, epi)
             return y
         h.call("lc_gemm_tile", w.data.data_ptr(), x.data_ptr(), y.data_ptr(), h.ptr(w.bias), M, w.n, w.k, w.n_pad,

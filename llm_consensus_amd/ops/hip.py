@@ -26,6 +26,7 @@ _SIGNATURES = {
     "lc_l2_normalize": [_P, _P, _I, _I, _P],
     "lc_gemm_tile": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "lc_gemm256": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
+    "lc_gemm256w": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "lc_gemm_panel": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     "lc_kgemm": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
     "lc_splitk_reduce": [_P, _P, _P, _I, _I, _I, _I, _I, _P],

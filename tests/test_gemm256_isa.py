@@ -98,3 +98,79 @@ def test_weights_in_registers_loop_has_no_copies_spills_or_uncounted_memory_ops(
         assert vmem.count("global_load_dwordx4") == 16 and vmem.count("global_load_lds_dwordx4") == 8, name
         waits = [l for l in loop if l.startswith("s_waitcnt") and "vmcnt" in l]
         assert len(waits) == 4 and all(re.search(r"vmcnt\((12|14)\)", w) for w in waits), (name, waits)
+
+
+@pytest.mark.skipif(not shutil.which(HIPCC), reason="hipcc not installed")
+def test_four_wave_loop_keeps_accumulators_in_place_and_counts_its_requests(tmp_path):
+    """csrc/kernels/gemm256w.hip: one wave per SIMD, 64 accumulator tiles in AGPRs, inline-assembly
+    MFMAs and weight loads, hand-counted waits two K-tiles deep. Checked in the generated code: the
+    steady-state loop (two K-tiles, 256 MFMAs) accumulates in place in AGPRs (no accumulator copies),
+    spills nothing, issues exactly the 32 weight loads and 16 LDS-DMA the counts assume, and every
+    register a load targets is next read by an MFMA after a wait that covers that load."""
+    out = tmp_path / "gemm256w.s"
+    subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-math-errno", "-ffp-contract=fast",
+                    "-fno-gpu-rdc", f"-I{ROOT / 'csrc' / 'kernels'}", "--cuda-device-only", "-S",
+                    str(ROOT / "csrc" / "kernels" / "gemm256w.hip"), "-o", str(out)], check=True, timeout=600)
+    text = out.read_text()
+    kernels = re.findall(r"^(_ZN\S*gemm256w_kernelILi\dEE[^:\s]*):[^\n]*\n(.*?)^\.Lfunc_end", text, re.S | re.M)
+    assert len(kernels) == 2, "expected the bf16 and SwiGLU instantiations"
+    for name, body in kernels:
+        raw = [l.strip() for l in body.splitlines() if l.strip() and not l.strip().startswith(";")]
+        loop = None
+        for i, l in enumerate(raw):
+            m = re.match(r"(\.LBB\d+_\d+):", l)
+            if not m:
+                continue
+            for j in range(i + 1, len(raw)):
+                if re.match(r"\.LBB\d+_\d+:", raw[j]):
+                    break
+                if raw[j].startswith("s_cbranch") and raw[j].split()[-1] == m.group(1):
+                    body_ij = raw[i + 1: j]
+                    if sum(x.startswith("v_mfma") for x in body_ij) == 256:
+                        loop = body_ij
+                    break
+            if loop:
+                break
+        assert loop is not None, f"{name}: steady-state loop of 256 MFMAs not found"
+        assert not any(l.startswith(("scratch_", "v_accvgpr")) for l in loop), f"{name}: spills or accumulator copies"
+        accs = set()
+        for l in loop:
+            if l.startswith("v_mfma"):
+                m = re.match(r"v_mfma_f32_16x16x32_bf16 (a\[\d+:\d+\]), v\[\d+:\d+\], v\[\d+:\d+\], (a\[\d+:\d+\])$", l)
+                assert m and m.group(1) == m.group(2), f"{name}: not an in-place AGPR accumulate: {l}"
+                accs.add(m.group(1))
+        assert len(accs) == 64, f"{name}: {len(accs)} accumulator tiles"
+        touched = []
+        for l in loop:
+            op, *rest = l.replace(",", " ").split()
+            t = set()
+            for tok in rest:
+                t |= _regs(tok)
+            touched.append((op, t))
+        n = len(loop)
+        loaded = set()
+        for i, (op, t) in enumerate(touched):
+            if op != "global_load_dwordx4":
+                continue
+            dst = _regs(loop[i].split()[1].rstrip(","))
+            loaded |= dst
+            for r in dst:
+                younger, covered = 0, False
+                for k in range(1, n + 1):
+                    op2, t2 = touched[(i + k) % n]
+                    line2 = loop[(i + k) % n]
+                    if op2.startswith(("global_load", "buffer_load", "global_store", "buffer_store")):
+                        younger += 1
+                    elif op2 == "s_waitcnt":
+                        m = re.search(r"vmcnt\((\d+)\)", line2)
+                        covered = covered or (m is not None and int(m.group(1)) <= younger)
+                    if r in t2:
+                        assert op2.startswith("v_mfma"), f"{name}: v{r} is loaded by `{loop[i]}` and next touched by `{line2}`"
+                        assert covered, f"{name}: `{line2}` reads v{r} before a wait covers `{loop[i]}`"
+                        break
+        assert len(loaded) == 128, f"{name}: expected 32 weight fragments x 4 registers, found {len(loaded)}"
+        vmem = [l.split()[0] for l in loop if l.startswith(("global_", "buffer_", "flat_", "scratch_"))]
+        assert vmem.count("global_load_dwordx4") == 32 and vmem.count("global_load_lds_dwordx4") == 16, name
+        assert set(vmem) == {"global_load_dwordx4", "global_load_lds_dwordx4"}, (name, set(vmem))
+        waits = [l for l in loop if l.startswith("s_waitcnt") and "vmcnt" in l]
+        assert len(waits) == 4 and all(re.search(r"vmcnt\((32|40)\)", w) for w in waits), (name, waits)

@@ -89,6 +89,48 @@ def test_gemm256_pipelined(M, N, K, mode):
         ops.GEMM256_MIN_TILES, ops.WS_MAX_M = old
 
 
+@pytest.mark.parametrize("M,N,K", [(256, 256, 256), (700, 256, 4096), (1000, 1024, 896), (257, 768, 1088), (512, 480, 320),
+                                   (300, 512, 8192)])
+@pytest.mark.parametrize("mode", ["bf16_bias", "swiglu"])
+def test_gemm256_four_wave(M, N, K, mode):
+    """The four-wave 256x256 kernel (128 x 128 per wave, accumulators in AGPRs, hand-placed
+    requests two K-tiles ahead): 4 to 128 K-tiles, even and odd counts (the loop is unrolled by two),
+    ragged M, an N that ends inside the last tile (direct-store epilogue), bias, SwiGLU; against the
+    fp32 reference and bit for bit against the eight-wave kernel, which accumulates in the same order."""
+    X = bf(rand(M, K, scale=0.5) + torch.arange(M)[:, None] * 1e-3)
+    old = ops.GEMM256_MIN_TILES, ops.WS_MAX_M, ops.GEMM256W_MIN_K, ops.GEMM256_MAX_SPLITS
+    ops.GEMM256_MIN_TILES, ops.WS_MAX_M, ops.GEMM256_MAX_SPLITS = 0, 0, 1     # whole-K tiles whatever their number
+    try:
+        if mode == "swiglu":
+            Wg, Wu = bf(rand(N // 2, K, scale=0.3, seed=3)), bf(rand(N // 2, K, scale=0.3, seed=4))
+            lw = ops.LinearWeight.from_dense(ops.interleave_gate_up(Wg, Wu), None, DEV, swiglu=True)
+            want = torch.nn.functional.silu(X.float() @ Wg.float().t()) * (X.float() @ Wu.float().t())
+            tol = 8e-3
+        else:
+            W = bf(rand(N, K, scale=0.5, seed=1) + torch.arange(N)[:, None] * 1e-3)
+            b = bf(rand(N, seed=2))
+            lw = ops.LinearWeight.from_dense(W, b, DEV)
+            want = ref.linear(X, W, b, torch.float32)
+            tol = 6e-3
+        xg = X.to(DEV)
+        ops.GEMM256W_MIN_K = 1 << 30
+        eight = ops.linear(xg, lw)
+        ops.GEMM256W_MIN_K = 1
+        from llm_consensus_amd.ops import hip as hipmod
+
+        rec = hipmod.start_recording()
+        try:
+            for _ in range(3):
+                got = ops.linear(xg, lw)
+                assert rel_err(got, want) < tol
+                assert torch.equal(got, eight)
+        finally:
+            hipmod.stop_recording()
+        assert {name for _, _, name in rec} == {"lc_gemm256w"}
+    finally:
+        ops.GEMM256_MIN_TILES, ops.WS_MAX_M, ops.GEMM256W_MIN_K, ops.GEMM256_MAX_SPLITS = old
+
+
 @pytest.mark.parametrize("M", [1, 16, 17, 33, 64])
 @pytest.mark.parametrize("N,K", [(256, 1024), (1152, 896), (128, 4096), (384, 192)])
 @pytest.mark.parametrize("ntw", [1, 2, 4])

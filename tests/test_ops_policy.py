@@ -22,3 +22,15 @@ def test_wide_panel_workgroups_only_where_they_save_a_round():
         assert not ops.use_wide_panel(rows, 6144, 4096)                                      # QKV: K is split
     assert not ops.use_wide_panel(300, gate_up_cols("qwen2.5-7b"), q.hidden_size)
     assert ops.use_wide_panel(64, 320 * 128, 4096) and not ops.use_wide_panel(64, 321 * 128, 4096)
+
+
+def test_four_wave_prefill_gemm_for_long_reductions_only():
+    """The four-wave 256 x 256 kernel wins where its longer prologue is spread over many K-tiles
+    (measured: K = 14336 +3 %, K = 4096 -1..-4 %): the down projections take it, the projections
+    whose reduction runs over d_model do not, and fp32 outputs (split-K slabs) never do."""
+    for name in ("llama-3-8b", "qwen2.5-7b", "mistral-7b", "llama-3-70b"):
+        c = get_preset(name)
+        assert ops.use_four_wave_gemm(c.intermediate_size)          # down: K = intermediate size
+        assert not ops.use_four_wave_gemm(c.hidden_size) or c.hidden_size >= 8192   # QKV / O / gate-up
+        assert not ops.use_four_wave_gemm(c.intermediate_size, out_f32=True)
+    assert not ops.use_four_wave_gemm(4096) and ops.use_four_wave_gemm(8192)
