@@ -13,10 +13,11 @@ LAST line of its output. As soon as the headline workload is measured, and again
 further section, it also prints the line as it stands so far (marked ``"provisional"``): a run
 that is cut short by a time limit has still reported everything it measured.
 
-Time budget on a multi-GPU node (defaults): A, B and C take ~150 s; the sections that run in
-child processes (A with one model per GPU, D, E) share ``--isolated-budget`` 390 s, each attempt
-at most ``--section-timeout`` 150 s, and an attempt is only started with a minute left: the
-whole run stays under 150 + 390 = 540 s whatever stalls. A model group's own collectives give
+Time budget on a multi-GPU node (defaults): A, B and C take ~180 s (C with 32 questions in
+flight and four timed steps); the sections that run in child processes (A with one model per
+GPU, D, E) share ``--isolated-budget`` 360 s, each attempt at most ``--section-timeout`` 150 s,
+and an attempt is only started with a minute left: the whole run stays under 180 + 360 = 540 s
+whatever stalls. A model group's own collectives give
 up waiting for a peer after LC_P2P_TIMEOUT_S (10 s here) and a group whose first exchange fails
 its self-check falls back to RCCL inside the same process (parallel/p2p.py).
 
@@ -52,6 +53,7 @@ import sys
 import time
 from pathlib import Path
 
+T_START = time.perf_counter()
 ROOT = Path(__file__).resolve().parent
 if str(ROOT) not in sys.path:
     sys.path.insert(0, str(ROOT))
@@ -113,7 +115,7 @@ def parse_args(argv=None):
                     help="multi-GPU runs: skip the extra run of workload A with one model per GPU")
     ap.add_argument("--section-timeout", type=float, default=150.0,
                     help="multi-GPU runs: seconds a sharded workload (D, E) may take before it is abandoned")
-    ap.add_argument("--isolated-budget", type=float, default=390.0,
+    ap.add_argument("--isolated-budget", type=float, default=360.0,
                     help="multi-GPU runs: seconds all child-process sections together may take; what is left "
                          "bounds each attempt, and a section that finds less than a minute left is skipped")
     ap.add_argument("--share-gpu", action="store_true",
@@ -289,6 +291,7 @@ def emit(ctx: Ctx, out: dict, pending: str = "") -> None:
         d["vs_baseline"] = round(d["value"] / REFERENCE_BOUND_ANSWERS_PER_S, 1)
     if pending:
         d["provisional"] = f"still to come: {pending}"
+    d["elapsed_s"] = round(time.perf_counter() - T_START, 1)      # since this rank started (imports included)
     line = json.dumps(d)
     print(line, flush=True)
     if ctx.a.out:
