@@ -25,14 +25,20 @@ def graph_time(fns, reps=3):
         for _ in range(reps):
             for f in fns:
                 f()
-    g.replay()
+    # the first replays run while the clocks are still coming up from idle (the first shape of a
+    # run measured ~15 % slow with a single untimed replay): warm for ~50 ms, then take the median
+    for _ in range(8):
+        g.replay()
     torch.cuda.synchronize()
-    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    s.record()
-    g.replay()
-    e.record()
-    torch.cuda.synchronize()
-    return s.elapsed_time(e) / (reps * len(fns)) * 1e3
+    times = []
+    for _ in range(5):
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        g.replay()
+        e.record()
+        torch.cuda.synchronize()
+        times.append(s.elapsed_time(e))
+    return sorted(times)[len(times) // 2] / (reps * len(fns)) * 1e3
 
 
 def main():
