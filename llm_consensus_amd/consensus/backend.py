@@ -46,9 +46,10 @@ class GenResult:
 class Handle:
     """Result slot for one submitted request."""
 
-    __slots__ = ("_value", "_error", "_done", "submitted_at", "finished_at", "tag", "usage")
+    __slots__ = ("_value", "_error", "_done", "submitted_at", "finished_at", "tag", "usage", "backend")
 
     def __init__(self, tag: Any = None) -> None:
+        self.backend: Optional["Backend"] = None     # set by backends that can cancel (see cancel())
         # (prompt tokens, completion tokens, prompt tokens served from the prefix cache) of the
         # call, when the backend counts tokens; summed into ConsensusResult.usage
         self.usage: Optional[tuple] = None
@@ -70,6 +71,15 @@ class Handle:
     @property
     def done(self) -> bool:
         return self._done
+
+    def cancel(self) -> bool:
+        """Asks the backend to stop working on this request (its caller has gone away). Returns
+        whether the backend took the request; the handle then completes with an error at the
+        backend's next step. A finished handle, or one of a backend that cannot cancel, is left
+        alone. Call from the thread that drives the backend."""
+        if self._done or self.backend is None:
+            return False
+        return self.backend.cancel(self)
 
     @property
     def failed(self) -> bool:
@@ -120,6 +130,12 @@ class Backend:
     def fail_pending(self, err: BaseException) -> None:
         """Completes every outstanding handle with ``err`` (used by drivers that step this
         backend's engines themselves and caught a failure)."""
+
+    def cancel(self, handle: Handle) -> bool:
+        """Stops work on one submitted request, where a backend can (the reference cannot: a call
+        to its remote model runs to the end whoever still waits for it,
+        /root/reference/src/main.rs:82-86). The default cannot."""
+        return False
 
     def run_local(self) -> None:
         """Compute phase of run(): everything that needs no other backend's ranks."""

@@ -285,6 +285,16 @@ class SessionPool:
             time.sleep(20e-6)
         return finished
 
+    def cancel(self, ticket: int) -> bool:
+        """Drops a session whose caller has gone away: the member calls it waits for are cancelled
+        where the backends can, and it produces no result."""
+        L = self.live.pop(ticket, None)
+        if L is None:
+            return False
+        for h in L.handles:
+            h.cancel()
+        return True
+
     def drain(self) -> List[tuple]:
         out = []
         while self.live:

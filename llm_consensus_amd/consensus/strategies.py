@@ -277,6 +277,16 @@ class VotePool:
             time.sleep(20e-6)
         return finished
 
+    def cancel(self, ticket: int) -> bool:
+        """Drops a question whose caller has gone away: its member calls are cancelled where the
+        backends can (the engines free their KV blocks at the next step) and no result is produced."""
+        row = self.live.pop(ticket, None)
+        if row is None:
+            return False
+        for h in row[1]:
+            h.cancel()
+        return True
+
     def drain(self) -> List[tuple]:
         out = []
         while self.live:
@@ -669,6 +679,16 @@ class PhasedPool:
         if self.live and not self.stepper.step() and not finished:
             time.sleep(20e-6)
         return finished
+
+    def cancel(self, ticket: int) -> bool:
+        """Drops a question whose caller has gone away (see VotePool.cancel)."""
+        e = self.live.pop(ticket, None)
+        if e is None:
+            return False
+        hs = list(self.s._first_handles(e[3])) + (list(self.s._second_handles(e[3])) if e[2] == 2 else [])
+        for h in hs:
+            h.cancel()
+        return True
 
     def drain(self) -> List[tuple]:
         out = []

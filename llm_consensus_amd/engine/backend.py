@@ -51,6 +51,7 @@ class EngineBackend(Backend):
             dec = [self.tok.first_token_id(t) for t in params.decision_targets] if params.decision_targets else None
             rid = self.engine.submit(ids, core.RequestKind.Generate, max(1, params.n), self._params(params), dec)
             self._pending[rid] = ("gen", h)
+            h.backend = self
             if on_text is not None:
                 self._streams[rid] = [on_text, [""] * max(1, params.n)]   # callback, text already sent per chain
         except Exception as e:  # a bad request fails that member only
@@ -67,6 +68,7 @@ class EngineBackend(Backend):
             tids = [self.tok.first_token_id(t) for t in targets]
             rid = self.engine.submit(ids, core.RequestKind.Score, score_ids=tids)
             self._pending[rid] = ("score", h)
+            h.backend = self
         except Exception as e:
             h.set_error(e)
         return h
@@ -76,6 +78,7 @@ class EngineBackend(Backend):
         try:
             rid = self.engine.submit(self.tok.encode(text), core.RequestKind.Embed)
             self._pending[rid] = ("embed", h)
+            h.backend = self
         except Exception as e:
             h.set_error(e)
         return h
@@ -122,6 +125,19 @@ class EngineBackend(Backend):
 
     def fail_pending(self, err: BaseException) -> None:
         self._fail_all(err)
+
+    def cancel(self, handle: Handle) -> bool:
+        """The engine drops the request at its next step boundary (waiting, prefilling or
+        decoding), its KV blocks go back to the pool, and the handle completes with an error.
+        Members of a tensor / expert parallel group cannot cancel on one rank alone."""
+        m = self.engine.model
+        if m.tp_size > 1 or m.ep_size > 1:
+            return False
+        for rid, (_, h) in self._pending.items():
+            if h is handle:
+                self._streams.pop(rid, None)
+                return self.engine.cancel(rid)
+        return False
 
     def _fail_all(self, e: BaseException) -> None:
         """An engine step raised: every request in flight gets the error (the protocol maps it
@@ -182,6 +198,10 @@ class EngineBackend(Backend):
                 continue
             del self._pending[rid]
             h.usage = (out.prompt_len, sum(len(t) for t in out.token_ids), out.cached_tokens)
+            if out.finish_reasons and all(r == "Aborted" for r in out.finish_reasons):
+                self._streams.pop(rid, None)
+                h.set_error(BackendError("cancelled"))
+                continue
             if rid in self._streams:
                 self._emit(rid, out.token_ids, final=True)
                 del self._streams[rid]

@@ -637,6 +637,7 @@ class Engine:
             self.stream.wait_stream(torch.cuda.current_stream(self.device))   # weights were written there
         self._graphs: Dict[tuple, _DecodeGraph] = {}
         self._reqs: Dict[int, _ReqState] = {}
+        self._cancel: set = set()       # requests to drop at the next step boundary (cancel())
         self._done: Dict[int, RequestOutput] = {}
         self._last_dec = None   # (request ids, chain seeds, decision log-probs) of the newest decode step
         self.metrics = core.Metrics()
@@ -664,6 +665,30 @@ class Engine:
     def has_work(self) -> bool:
         return self.sched.has_work()
 
+    def cancel(self, rid: int) -> bool:
+        """Marks one request for removal: at the next step boundary (no step of this engine on
+        the GPU) it leaves the scheduler whatever its state (waiting, prefilling, decoding), its
+        KV blocks return to the pool and its result comes out with finish reason ``Aborted``.
+        Returns False for a request the engine does not hold (any more). Call from the thread
+        that steps the engine."""
+        if rid not in self._reqs:
+            return False
+        self._cancel.add(rid)
+        return True
+
+    def _apply_cancels(self) -> None:
+        rids, self._cancel = [r for r in self._cancel if r in self._reqs], set()
+        if not rids:
+            return
+        for rid in rids:
+            self.sched.abort_request(rid)
+        self._collect()
+        # cached views of the decode batch (row layout, decision rows) name rows that are gone
+        self._dec_cache = None
+        for g in self._graphs.values():
+            g.rows_key = None
+        self.metrics.inc("requests.cancelled", len(rids))
+
     def abort_all(self) -> int:
         """Drops every request the engine holds (waiting, prefilling or decoding) and returns
         their KV blocks: the recovery path after a failed step, whose requests cannot be
@@ -678,6 +703,7 @@ class Engine:
         self.kvm.take_pending_copies()
         self.kvm.drop_cache()
         self._reqs.clear()
+        self._cancel.clear()
         self._last_dec = None
         self._ahead = None
         self._dec_cache = None
@@ -790,6 +816,8 @@ class Engine:
         ``end_step`` already launched the next decode step, that step's plan is returned."""
         if self._ahead is not None:
             return self._ahead[0]
+        if self._cancel:
+            self._apply_cancels()
         t0 = time.perf_counter()
         plan = self.sched.schedule()
         self.metrics.inc("host.schedule_seconds", time.perf_counter() - t0)
@@ -818,6 +846,8 @@ class Engine:
 
     def _launch_ahead(self, plan) -> None:
         """While the decode step ``plan`` is on the GPU: plans and launches the step after it."""
+        if self._cancel:
+            return            # a cancelled request leaves at a step boundary: let this step be the last in flight
         t0 = time.perf_counter()
         nxt = self.sched.schedule_ahead(plan)
         self.metrics.inc("host.schedule_seconds", time.perf_counter() - t0)

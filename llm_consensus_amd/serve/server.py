@@ -28,11 +28,19 @@ Routes
     POST /v1/embeddings          pooled, L2-normalised embeddings from a member model
 Consensus responses carry an extra ``consensus`` object (votes, rounds, agreement,
 unanimity) next to the OpenAI fields.
+
+A client that hangs up (closes its socket while it waits for an answer, or in the middle of a
+token stream) is noticed within a quarter of a second; in continuous mode its work is cancelled:
+the engines drop its requests at their next step boundary and their KV blocks return to the pool
+(``cancelled_total`` in /metrics, ``requests.cancelled`` per engine). Members that are sharded
+over a tensor / expert parallel group run such a request to its end.
 """
 from __future__ import annotations
 
 import json
 import queue
+import select
+import socket
 import threading
 import time
 import uuid
@@ -58,6 +66,7 @@ class _Job:
     chunks: Optional["queue.Queue"] = None
     result: Any = None
     error: Optional[str] = None
+    cancelled: bool = False          # the client went away before its answer: stop working on it
     t_submit: float = field(default_factory=time.perf_counter)
 
 
@@ -75,8 +84,10 @@ class ConsensusServer:
         self.max_batch, self.window = max_batch, batch_window_ms / 1e3
         self.request_timeout_s = request_timeout_s
         self.jobs: "queue.Queue[_Job]" = queue.Queue()
+        self.cancels: "queue.Queue[_Job]" = queue.Queue()      # jobs whose client disconnected (see _cancel)
         self.counters: Dict[str, float] = {"requests_total": 0, "errors_total": 0, "batches_total": 0,
-                                           "batched_requests_total": 0, "latency_seconds_sum": 0.0}
+                                           "batched_requests_total": 0, "latency_seconds_sum": 0.0,
+                                           "cancelled_total": 0}
         self._lock = threading.Lock()
         self._stop = threading.Event()
         server = self
@@ -180,7 +191,25 @@ class ConsensusServer:
                 with self._lock:
                     self.counters["batches_total"] += 1
                     self.counters["batched_requests_total"] += len(new)
+            while True:                     # clients that went away: their work leaves the engines
+                try:
+                    gone = self.cancels.get_nowait()
+                except queue.Empty:
+                    break
+                for t, j in list(tickets.items()):
+                    if j is gone:
+                        pool.cancel(t)
+                        del tickets[t]
+                        j.error = "cancelled"
+                        self._finish(j)
+                for h_, j in direct:
+                    if j is gone:
+                        h_.cancel()         # completes with an error at the engine's next step
             for j in new:
+                if j.cancelled:
+                    j.error = "cancelled"
+                    self._finish(j)
+                    continue
                 try:
                     if j.kind == "consensus":
                         tickets[pool.submit(j.text)] = j
@@ -196,7 +225,10 @@ class ConsensusServer:
                 finished = pool.pump()
                 # The pool advances the shared stepper while it has questions; when it is idle the
                 # direct requests are advanced here, through the same stepper.
-                if not was_active and direct:
+                # ... and so are the leftovers of cancelled requests: an engine lets them go at its
+                # next step boundary, which has to come even if nobody else waits for that engine.
+                leftovers = not was_active and not direct and any(b.engines() for b in stepper.backends)
+                if not was_active and (direct or leftovers):
                     if not stepper.step():
                         time.sleep(20e-6)
             except Exception as e:  # noqa: BLE001  never let the driver die with waiters parked on it
@@ -328,10 +360,42 @@ class ConsensusServer:
             except BackendError as e:
                 j.error = str(e)
 
-    def submit(self, job: _Job) -> _Job:
+    def _cancel(self, job: _Job) -> None:
+        """The client of ``job`` is gone: the serving loop takes its work out of the engines (KV
+        blocks freed at the next step) instead of finishing an answer nobody will read. The
+        reference cannot stop a member call once it is sent (/root/reference/src/main.rs:82-86)."""
+        if job.cancelled or job.done.is_set():
+            return
+        job.cancelled = True
+        with self._lock:
+            self.counters["cancelled_total"] += 1
+        if self.continuous:
+            self.cancels.put(job)
+
+    @staticmethod
+    def _peer_closed(conn) -> bool:
+        """True once the client has closed its end (end of stream readable on the socket)."""
+        try:
+            r, _, _ = select.select([conn], [], [], 0)
+            if not r:
+                return False
+            return conn.recv(1, socket.MSG_PEEK | socket.MSG_DONTWAIT) == b""
+        except (BlockingIOError, InterruptedError):
+            return False
+        except (OSError, ValueError):
+            return True
+
+    def submit(self, job: _Job, conn=None) -> _Job:
+        """Queues ``job`` and waits for it. With ``conn`` (the request's socket) the wait also
+        watches for the client hanging up, and cancels the job if it does."""
         self.jobs.put(job)
-        if not job.done.wait(self.request_timeout_s):
-            raise HTTPError(504, "request timed out in the engine queue")
+        deadline = time.perf_counter() + self.request_timeout_s
+        while not job.done.wait(0.25 if conn is not None else self.request_timeout_s):
+            if conn is not None and self._peer_closed(conn):
+                self._cancel(job)
+                raise HTTPError(499, "client closed the connection")
+            if time.perf_counter() >= deadline:
+                raise HTTPError(504, "request timed out in the engine queue")
         if job.error:
             raise HTTPError(500, job.error)
         return job
@@ -366,8 +430,11 @@ class ConsensusServer:
         except HTTPError as e:
             with self._lock:
                 self.counters["errors_total"] += 1
-            self._send_json(h, e.status, {"error": {"message": e.message, "type": "invalid_request_error"
-                                                    if e.status < 500 else "server_error", "code": e.status}})
+            try:
+                self._send_json(h, e.status, {"error": {"message": e.message, "type": "invalid_request_error"
+                                                        if e.status < 500 else "server_error", "code": e.status}})
+            except (BrokenPipeError, ConnectionResetError):
+                pass                     # the client this error is for has gone (status 499 always ends here)
         except (BrokenPipeError, ConnectionResetError):
             pass
         finally:
@@ -457,7 +524,7 @@ class ConsensusServer:
         created = int(time.time())
         if body.get("stream") and not consensus:
             return self._stream_tokens(h, rid, created, model, text, params, chat)
-        job = self.submit(_Job("consensus" if consensus else "generate", model, text, params))
+        job = self.submit(_Job("consensus" if consensus else "generate", model, text, params), h.connection)
         extra: Dict[str, Any] = {}
         if consensus:
             r = job.result
@@ -508,10 +575,21 @@ class ConsensusServer:
 
         started = set()
         deadline = time.perf_counter() + self.request_timeout_s
+        try:
+            self._stream_tokens_body(h, job, emit, started, deadline, chat)
+        except (BrokenPipeError, ConnectionResetError):
+            self._cancel(job)           # nobody reads the stream any more: stop generating
+            raise
+
+    def _stream_tokens_body(self, h, job, emit, started, deadline, chat) -> None:
         while True:
             try:
-                item = job.chunks.get(timeout=max(0.0, deadline - time.perf_counter()))
+                item = job.chunks.get(timeout=min(0.25, max(0.0, deadline - time.perf_counter())))
             except queue.Empty:
+                if time.perf_counter() < deadline:
+                    if self._peer_closed(h.connection):     # hung up between two tokens
+                        raise BrokenPipeError("client closed the connection")
+                    continue
                 emit({"index": 0, "delta": {}, "finish_reason": "error"}, error={"message": "request timed out"})
                 break
             if item is None:

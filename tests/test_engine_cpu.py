@@ -173,3 +173,66 @@ def test_step_staging_packs_arrays_of_mixed_dtypes_and_grows():
             assert np.array_equal(v.numpy(), a)
     with pytest.raises(TypeError):
         sg.put(np.zeros(3, dtype=np.float64))
+
+
+@pytest.mark.parametrize("pipeline", [True, False])
+def test_cancelled_requests_leave_at_a_step_boundary_and_free_their_blocks(pipeline):
+    """Engine.cancel: a decoding request, a request in the middle of a chunked prefill and a
+    waiting request are dropped at the next step boundary (with decode steps launched ahead of
+    their results or not), their KV blocks return to the pool, their results come out as Aborted,
+    and the requests that stay produce exactly the tokens of a run that never saw the others."""
+    cfg = get_preset("tiny-llama")
+    model = TransformerModel.random_init(cfg, "cpu", seed=9, std=0.1)
+    rng = np.random.default_rng(3)
+    prompts = [rng.integers(5, 250, size=n).tolist() for n in (40, 33, 70, 52, 90)]
+
+    def engine():
+        return Engine(model, num_kv_blocks=96, block_size=16, max_batch_seqs=3, max_prefill_tokens=48, use_graphs=False,
+                      pipeline_decode=pipeline, enable_prefix_cache=False)
+
+    ref_eng = engine()
+    keep = [ref_eng.submit(prompts[i], params=greedy_params(12, seed=10 + i, temperature=0.8)) for i in (0, 3)]
+    ref_eng.run_until_done()
+    want = [ref_eng.pop_result(r).token_ids for r in keep]
+
+    eng = engine()
+    rids = [eng.submit(p, n=2 if i == 1 else 1, params=greedy_params(12, seed=10 + i, temperature=0.8))
+            for i, p in enumerate(prompts)]
+    free0 = eng.stats()["kv.blocks_free"]
+    for _ in range(3):                               # 0 and 1 decode, 2 is part-way through its prefill, 3 and 4 wait
+        eng.step()
+    assert eng.stats()["sched.waiting"] >= 1
+    assert eng.cancel(rids[1]) and eng.cancel(rids[2]) and eng.cancel(rids[4])
+    assert not eng.cancel(10 ** 6)
+    eng.run_until_done()
+    outs = [eng.pop_result(r) for r in rids]
+    for i in (1, 2, 4):
+        assert set(outs[i].finish_reasons) == {"Aborted"}
+    assert [outs[0].token_ids, outs[3].token_ids] == want
+    st = eng.stats()
+    assert st["requests.cancelled"] == 3 and st["kv.blocks_free"] == free0 == st["kv.blocks_total"]
+    assert not eng.cancel(rids[0])                   # finished requests are not the engine's any more
+
+
+def test_backend_handle_cancel_completes_the_handle_with_an_error():
+    from llm_consensus_amd.consensus.backend import BackendError, GenParams
+    from llm_consensus_amd.engine.backend import EngineBackend
+    from llm_consensus_amd.utils.tokenizer import ByteLevelTokenizer
+
+    cfg = get_preset("tiny-llama")
+    model = TransformerModel.random_init(cfg, "cpu", seed=9, std=0.1)
+    be = EngineBackend(Engine(model, num_kv_blocks=96, block_size=16, use_graphs=False), ByteLevelTokenizer(cfg.vocab_size),
+                       stop_at_eos=False)
+    a = be.submit_generate("first question " * 3, GenParams(temperature=0.0, max_new_tokens=30))
+    b = be.submit_generate("second question " * 3, GenParams(temperature=0.0, max_new_tokens=8))
+    for _ in range(3):
+        be.poll()
+    assert a.cancel() and not a.done
+    while be.poll():
+        pass
+    assert a.done and a.failed and b.done and not b.failed and len(b.result().token_ids[0]) == 8
+    with pytest.raises(BackendError, match="cancelled"):
+        a.result()
+    assert not a.cancel() and not b.cancel()         # finished handles stay as they are
+    st = be.engine.stats()                           # nothing is held but what the prefix cache keeps for reuse
+    assert st["kv.blocks_free"] + st["kv.blocks_cached"] == st["kv.blocks_total"] and st["requests.cancelled"] == 1

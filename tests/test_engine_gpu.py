@@ -434,3 +434,41 @@ def test_serving_steps_launch_only_the_kernel_library():
         torch.cuda.synchronize()
     assert all(r.answer in "ABCD" for r in res) and outs[2].embedding is not None and len(outs[1].scores) == 5
     assert audit.kernels == {}, audit.kernels
+
+
+def test_cancel_under_recorded_decode_steps_launched_ahead():
+    """Engine.cancel on the serving configuration: decode steps replayed from hipGraphs and
+    launched ahead of their results. Requests are cancelled while decoding, while another is in
+    the middle of its chunked prefill and while one still waits; they come out Aborted, every KV
+    block returns to the pool, the other requests run to their full length, and a request admitted
+    afterwards is served from a clean state (same tokens as on a fresh engine)."""
+    cfg = get_preset("small-llama")
+    model = TransformerModel.random_init(cfg, "cuda", seed=4, std=0.05)
+    rng = np.random.default_rng(1)
+    prompts = [rng.integers(5, 3000, size=n).tolist() for n in (300, 120, 700, 90, 400)]
+
+    def engine():
+        return Engine(model, num_kv_blocks=128, block_size=64, max_batch_seqs=4, max_prefill_tokens=512,
+                      enable_prefix_cache=False)
+
+    eng = engine()
+    assert eng.use_graphs and eng.pipeline_decode
+    rids = [eng.submit(p, n=2 if i == 1 else 1, params=params(40, seed=i)) for i, p in enumerate(prompts)]
+    total = eng.stats()["kv.blocks_total"]
+    for _ in range(6):
+        eng.step()
+    assert eng.cancel(rids[1]) and eng.cancel(rids[2]) and eng.cancel(rids[4])
+    eng.run_until_done()
+    outs = [eng.pop_result(r) for r in rids]
+    for i in (1, 2, 4):
+        assert set(outs[i].finish_reasons) == {"Aborted"}
+    for i in (0, 3):
+        assert outs[i].finish_reasons == ["Length"] and len(outs[i].token_ids[0]) == 40
+    st = eng.stats()
+    assert st["requests.cancelled"] == 3 and st["kv.blocks_free"] == total and st["decode.ahead_steps"] > 0
+    again = eng.submit(prompts[3], params=params(12, seed=3))
+    eng.run_until_done()
+    fresh = engine()
+    ref = fresh.submit(prompts[3], params=params(12, seed=3))
+    fresh.run_until_done()
+    assert eng.pop_result(again).token_ids == fresh.pop_result(ref).token_ids

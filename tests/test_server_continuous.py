@@ -113,3 +113,55 @@ def test_streamed_text_that_diverges_after_a_preemption_is_restarted_not_silence
     assert got[0] == (0, "The answer") and got[1] == (0, " is")
     assert got[2] == (0, EngineBackend.RESTART_MARKER + "The reply is B")
     assert got[3] == (0, ".") and len(got) == 4
+
+
+def test_a_client_that_hangs_up_takes_its_work_out_of_the_engine():
+    """A streaming completion whose client closes the socket after the first tokens, and a
+    consensus question whose client gives up while it waits: the serving loop cancels both (the
+    engine drops their requests at its next step and frees their blocks) instead of generating to
+    the end for nobody, and a request that arrives afterwards is served as usual."""
+    import socket
+
+    cfg = config_from_dict({"strategy": "majority_vote", "seed": 3,
+                            "sampling": {"temperature": 0.0, "max_new_tokens": 400},
+                            "models": {"default": {"preset": "tiny-llama", "seed": 1, "kv_blocks": 512}}})
+    ens = build_ensemble(cfg)
+    srv = ConsensusServer(ens, port=0, max_batch=8).start()
+    eng = next(iter(ens.backends.values())).engine
+    try:
+        def raw_post(path, body):
+            s = socket.create_connection(("127.0.0.1", srv.port))
+            data = json.dumps(body).encode()
+            s.sendall(f"POST {path} HTTP/1.1\r\nHost: x\r\nContent-Type: application/json\r\n"
+                      f"Content-Length: {len(data)}\r\n\r\n".encode() + data)
+            return s
+
+        # 1. token stream: read until the first data chunk, then hang up
+        model = next(iter(ens.backends))
+        s1 = raw_post("/v1/completions", {"model": model, "prompt": "tell me a long story", "stream": True,
+                                          "max_tokens": 400})
+        got = b""
+        while b"data: " not in got:
+            got += s1.recv(4096)
+        s1.close()
+        # 2. consensus question (not streamed): hang up while it is being answered
+        s2 = raw_post("/v1/chat/completions", {"messages": [{"role": "user", "content": "A) x B) y C) z D) w ?"}]})
+        time.sleep(0.3)
+        s2.close()
+        deadline = time.time() + 60
+        while time.time() < deadline:
+            st = eng.stats()
+            if st.get("requests.cancelled", 0) >= 2 and st["sched.running"] == 0 and st["sched.waiting"] == 0:
+                break
+            time.sleep(0.05)
+        st = eng.stats()
+        assert st.get("requests.cancelled", 0) >= 2, st
+        assert st["sched.running"] == 0 and st["sched.waiting"] == 0
+        assert srv.counters["cancelled_total"] == 2
+        # far fewer tokens were generated than the 400 per member call that were asked for (5 calls)
+        assert st["decode.tokens"] < 1200, st["decode.tokens"]
+        # 3. the server still serves
+        code, out = _post(srv.port, "/v1/completions", {"model": model, "prompt": "hi", "max_tokens": 3})
+        assert code == 200 and out["usage"]["completion_tokens"] == 3
+    finally:
+        srv.shutdown()
