@@ -85,6 +85,7 @@ class ConsensusServer:
         self.request_timeout_s = request_timeout_s
         self.jobs: "queue.Queue[_Job]" = queue.Queue()
         self.cancels: "queue.Queue[_Job]" = queue.Queue()      # jobs whose client disconnected (see _cancel)
+        self._cancels_served = False     # only the single-process continuous driver takes work out of engines
         self.counters: Dict[str, float] = {"requests_total": 0, "errors_total": 0, "batches_total": 0,
                                            "batched_requests_total": 0, "latency_seconds_sum": 0.0,
                                            "cancelled_total": 0}
@@ -167,6 +168,7 @@ class ConsensusServer:
         # be stepped from two drivers (a step the pool's driver has in flight would be followed by
         # a second schedule() from a direct poll before its results were applied).
         stepper = BackendStepper(list({id(b): b for b in self.ensemble.backends.values()}.values()))
+        self._cancels_served = True
 
         def new_pool():
             p = self.ensemble.strategy.pool()
@@ -369,7 +371,7 @@ class ConsensusServer:
         job.cancelled = True
         with self._lock:
             self.counters["cancelled_total"] += 1
-        if self.continuous:
+        if self._cancels_served:
             self.cancels.put(job)
 
     @staticmethod
