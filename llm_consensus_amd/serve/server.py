@@ -29,6 +29,9 @@ Routes
 Consensus responses carry an extra ``consensus`` object (votes, rounds, agreement,
 unanimity) next to the OpenAI fields.
 
+At most ``max_pending`` requests are accepted at a time (answered or not yet): one more gets
+429 with a Retry-After header instead of an unbounded wait behind engines that are already full.
+
 A client that hangs up (closes its socket while it waits for an answer, or in the middle of a
 token stream) is noticed within a quarter of a second; in continuous mode its work is cancelled:
 the engines drop its requests at their next step boundary and their KV blocks return to the pool
@@ -78,17 +81,22 @@ class HTTPError(Exception):
 
 class ConsensusServer:
     def __init__(self, ensemble, host: str = "127.0.0.1", port: int = 8000, max_batch: int = 64,
-                 batch_window_ms: float = 5.0, request_timeout_s: float = 600.0, continuous: bool = True) -> None:
+                 batch_window_ms: float = 5.0, request_timeout_s: float = 600.0, continuous: bool = True,
+                 max_pending: int = 4096) -> None:
         self.ensemble = ensemble
         self.continuous = continuous
         self.max_batch, self.window = max_batch, batch_window_ms / 1e3
         self.request_timeout_s = request_timeout_s
+        # Admission limit: requests accepted and not yet answered. One more is refused with 429 and a
+        # Retry-After instead of queueing without bound behind work that already fills the engines.
+        self.max_pending = max_pending
+        self._outstanding = 0
         self.jobs: "queue.Queue[_Job]" = queue.Queue()
         self.cancels: "queue.Queue[_Job]" = queue.Queue()      # jobs whose client disconnected (see _cancel)
         self._cancels_served = False     # only the single-process continuous driver takes work out of engines
         self.counters: Dict[str, float] = {"requests_total": 0, "errors_total": 0, "batches_total": 0,
                                            "batched_requests_total": 0, "latency_seconds_sum": 0.0,
-                                           "cancelled_total": 0}
+                                           "cancelled_total": 0, "rejected_total": 0}
         self._lock = threading.Lock()
         self._stop = threading.Event()
         server = self
@@ -422,13 +430,25 @@ class ConsensusServer:
                 body = json.loads(h.rfile.read(n) or b"{}")
             except json.JSONDecodeError as e:
                 raise HTTPError(400, f"invalid JSON body: {e}")
-            if path == "/v1/chat/completions":
-                return self._completion(h, body, chat=True)
-            if path == "/v1/completions":
-                return self._completion(h, body, chat=False)
-            if path == "/v1/embeddings":
+            if path not in ("/v1/chat/completions", "/v1/completions", "/v1/embeddings"):
+                raise HTTPError(404, f"no route {path}")
+            with self._lock:
+                admitted = self._outstanding < self.max_pending
+                if admitted:
+                    self._outstanding += 1
+                else:
+                    self.counters["rejected_total"] += 1
+            if not admitted:
+                raise HTTPError(429, f"{self.max_pending} requests are already in flight; retry later")
+            try:
+                if path == "/v1/chat/completions":
+                    return self._completion(h, body, chat=True)
+                if path == "/v1/completions":
+                    return self._completion(h, body, chat=False)
                 return self._embeddings(h, body)
-            raise HTTPError(404, f"no route {path}")
+            finally:
+                with self._lock:
+                    self._outstanding -= 1
         except HTTPError as e:
             with self._lock:
                 self.counters["errors_total"] += 1
@@ -445,6 +465,8 @@ class ConsensusServer:
 
     def _send(self, h, status: int, payload: bytes, ctype: str) -> None:
         h.send_response(status)
+        if status == 429:
+            h.send_header("Retry-After", "1")
         h.send_header("Content-Type", ctype)
         h.send_header("Content-Length", str(len(payload)))
         h.end_headers()
@@ -466,6 +488,7 @@ class ConsensusServer:
                 lines.append(f"# TYPE consensus_http_{k} counter")
                 lines.append(f"consensus_http_{k} {v}")
         lines.append(f"consensus_http_queue_depth {self.jobs.qsize()}")
+        lines.append(f"consensus_http_requests_in_flight {self._outstanding}")
         for name, st in self.ensemble.stats().items():
             for k, v in st.items():
                 if isinstance(v, (int, float)):
@@ -681,6 +704,8 @@ def main(argv: Optional[list] = None) -> int:
     ap.add_argument("--port", type=int, default=8000)
     ap.add_argument("--max-batch", type=int, default=64)
     ap.add_argument("--batch-window-ms", type=float, default=5.0)
+    ap.add_argument("--max-pending", type=int, default=4096,
+                    help="requests accepted and not yet answered; one more gets 429 with Retry-After")
     ap.add_argument("--gpus", type=int, default=None,
                     help="run as this many ranks, one per GPU, started by this command (default: every replica "
                          "of the configured ensemble that the visible GPUs hold)")
@@ -725,7 +750,7 @@ def main(argv: Optional[list] = None) -> int:
         ens.warm_up()
     try:
         ConsensusServer(ens, args.host, args.port, args.max_batch, args.batch_window_ms,
-                        continuous=not args.batched).serve_forever()
+                        continuous=not args.batched, max_pending=args.max_pending).serve_forever()
     finally:
         if args.distributed:
             ens.close()

@@ -165,3 +165,33 @@ def test_a_client_that_hangs_up_takes_its_work_out_of_the_engine():
         assert code == 200 and out["usage"]["completion_tokens"] == 3
     finally:
         srv.shutdown()
+
+
+def test_requests_beyond_the_admission_limit_get_429_and_the_rest_are_answered():
+    import urllib.error
+    from concurrent.futures import ThreadPoolExecutor
+
+    cfg = config_from_dict({"strategy": "majority_vote", "seed": 3,
+                            "sampling": {"temperature": 0.0, "max_new_tokens": 60},
+                            "models": {"default": {"preset": "tiny-llama", "seed": 1, "kv_blocks": 512}}})
+    ens = build_ensemble(cfg)
+    srv = ConsensusServer(ens, port=0, max_batch=8, max_pending=3).start()
+    model = next(iter(ens.backends))
+    try:
+        def one(i):
+            try:
+                code, out = _post(srv.port, "/v1/completions", {"model": model, "prompt": f"question {i}", "max_tokens": 60})
+                return code, out["usage"]["completion_tokens"]
+            except urllib.error.HTTPError as e:
+                return e.code, e.headers.get("Retry-After")
+
+        with ThreadPoolExecutor(10) as ex:
+            got = list(ex.map(one, range(10)))
+        ok = [g for g in got if g[0] == 200]
+        busy = [g for g in got if g[0] == 429]
+        assert len(ok) + len(busy) == 10 and 3 <= len(ok) < 10 and busy, got
+        assert all(n == 60 for _, n in ok) and all(ra == "1" for _, ra in busy)
+        assert srv.counters["rejected_total"] == len(busy) and srv._outstanding == 0
+        assert one(99)[0] == 200                     # and the server is free again
+    finally:
+        srv.shutdown()
