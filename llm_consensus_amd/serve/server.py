@@ -405,6 +405,7 @@ class ConsensusServer:
                 self._cancel(job)
                 raise HTTPError(499, "client closed the connection")
             if time.perf_counter() >= deadline:
+                self._cancel(job)           # nobody waits for it any more
                 raise HTTPError(504, "request timed out in the engine queue")
         if job.error:
             raise HTTPError(500, job.error)
@@ -615,6 +616,7 @@ class ConsensusServer:
                     if self._peer_closed(h.connection):     # hung up between two tokens
                         raise BrokenPipeError("client closed the connection")
                     continue
+                self._cancel(job)
                 emit({"index": 0, "delta": {}, "finish_reason": "error"}, error={"message": "request timed out"})
                 break
             if item is None:
@@ -704,6 +706,8 @@ def main(argv: Optional[list] = None) -> int:
     ap.add_argument("--port", type=int, default=8000)
     ap.add_argument("--max-batch", type=int, default=64)
     ap.add_argument("--batch-window-ms", type=float, default=5.0)
+    ap.add_argument("--request-timeout", type=float, default=600.0,
+                    help="seconds a request may take before it is answered 504 and its work is cancelled")
     ap.add_argument("--max-pending", type=int, default=4096,
                     help="requests accepted and not yet answered; one more gets 429 with Retry-After")
     ap.add_argument("--gpus", type=int, default=None,
@@ -750,7 +754,8 @@ def main(argv: Optional[list] = None) -> int:
         ens.warm_up()
     try:
         ConsensusServer(ens, args.host, args.port, args.max_batch, args.batch_window_ms,
-                        continuous=not args.batched, max_pending=args.max_pending).serve_forever()
+                        request_timeout_s=args.request_timeout, continuous=not args.batched,
+                        max_pending=args.max_pending).serve_forever()
     finally:
         if args.distributed:
             ens.close()
