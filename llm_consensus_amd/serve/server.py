@@ -546,6 +546,13 @@ class ConsensusServer:
             if not isinstance(text, str) or not text:
                 raise HTTPError(400, "'prompt' must be a non-empty string")
         params = self._gen_params(body)
+        if params.max_new_tokens < 1 or params.n < 1:
+            raise HTTPError(400, "'max_tokens' and 'n' must be at least 1")
+        if not consensus:
+            limit = getattr(getattr(self.ensemble.backends[model], "engine", None), "max_model_len", None)
+            if limit is not None and params.max_new_tokens >= limit:
+                raise HTTPError(400, f"'max_tokens' = {params.max_new_tokens} leaves no room for a prompt in "
+                                     f"{model}'s context of {limit} tokens")
         rid = ("chatcmpl-" if chat else "cmpl-") + uuid.uuid4().hex[:24]
         created = int(time.time())
         if body.get("stream") and not consensus:

@@ -211,6 +211,9 @@ def test_a_request_that_times_out_is_answered_504_and_cancelled():
         with pytest.raises(urllib.error.HTTPError) as ei:
             _post(srv.port, "/v1/completions", {"model": model, "prompt": "a very long answer please", "max_tokens": 400})
         assert ei.value.code == 504
+        with pytest.raises(urllib.error.HTTPError) as bad:       # a budget the context cannot hold is the caller's error
+            _post(srv.port, "/v1/completions", {"model": model, "prompt": "x", "max_tokens": 10 ** 6})
+        assert bad.value.code == 400
         deadline = time.time() + 30
         while time.time() < deadline and eng.stats().get("requests.cancelled", 0) < 1:
             time.sleep(0.05)
