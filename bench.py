@@ -128,6 +128,10 @@ def parse_args(argv=None):
     if not wl or any(w not in ALL_WORKLOADS for w in wl):
         ap.error(f"--workload takes letters out of {ALL_WORKLOADS}")
     a.workloads = wl
+    if a.share_gpu and a.gpus > 1:
+        # rehearsal: all ranks allocate on ONE card, so the per-rank pools must add up to what a
+        # single GPU has (with 32 questions workload C alone reserves 43 GB of KV per rank)
+        a.proto_questions = min(a.proto_questions, 8)
     if a.aux_steps is None:
         # multi-GPU runs time fewer steps of C, D and E: their sections share a fixed time budget
         a.aux_steps = min(a.steps, 6 if a.gpus == 1 else 4)
@@ -533,6 +537,8 @@ def run_replica_workloads(ctx: Ctx, out: dict) -> None:
                 if i:
                     lat1.append(r1.latency_s * 1e3)
             out[key]["single_question_latency_ms"] = round(float(np.median(lat1)), 1)
+        del panel, solo, coord, be_p, eng_p          # the panel engine's KV pool goes back before D and E load their models
+        ctx.free()
         section_done(ctx, out, "C")
 
 

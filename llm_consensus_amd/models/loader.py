@@ -179,7 +179,19 @@ def write_random_checkpoint(cfg: ModelConfig, path: str, seed: int = 0, std: flo
 
 def build_model(spec, device, tp_rank: int = 0, tp_size: int = 1, comm=None, ep_size: int = 1,
                 ep_mode: str = "allreduce") -> TransformerModel:
-    """From a config.ModelSpec: a checkpoint path wins; otherwise random-init of a preset."""
+    """From a config.ModelSpec: a checkpoint path wins; otherwise random-init of a preset. On a
+    GPU the rank's share of the weights must be free on the card before anything is allocated
+    (all processes counted): see runtime.require_hbm."""
+    import torch
+
+    dev = torch.device(device)
+    if dev.type == "cuda":
+        from .. import runtime
+        from .config import from_hf_config
+
+        mc = from_hf_config(spec.path) if getattr(spec, "path", None) else get_preset(spec.preset or "tiny-llama")
+        with torch.cuda.device(dev):
+            runtime.require_hbm(mc.weight_bytes() // max(1, tp_size, ep_size), f"model {getattr(spec, 'name', '?')}")
     if getattr(spec, "path", None):
         return load_model(spec.path, device, tp_rank, tp_size, comm, ep_size=ep_size, ep_mode=ep_mode)
     cfg = get_preset(spec.preset or "tiny-llama")

@@ -76,6 +76,18 @@ def current_stream_ptr() -> int:
     return torch.cuda.current_stream().cuda_stream
 
 
+HBM_HEADROOM_BYTES = 1 << 30      # what an arena reservation leaves free for everybody's small allocations
+
+
+def require_hbm(nbytes: int, what: str) -> None:
+    """Raises unless ``nbytes`` (plus headroom) are free on the current device, all processes
+    counted: the check in front of every large allocation that is not an Arena (model weights)."""
+    free, total = mem_info()
+    if nbytes > free - HBM_HEADROOM_BYTES:
+        raise DeviceRuntimeError(f"{what} needs {nbytes} bytes of HBM; {free} of {total} are free on this device "
+                                 f"(all processes counted)")
+
+
 def mem_info() -> Tuple[int, int]:
     """(free, total) bytes of the current device."""
     f, t = c_longlong(0), c_longlong(0)
@@ -98,6 +110,15 @@ class Arena:
     def __init__(self, nbytes: int, pinned: bool = False, device: Optional[torch.device] = None) -> None:
         self.pinned, self.device = pinned, device
         self.nbytes = int(nbytes)
+        if not pinned:
+            # Never ask for more than the card has free RIGHT NOW, other processes included. The
+            # driver may grant such a request by evicting another process's memory, which stalls
+            # that process's queues (two ranks rehearsing on one GPU did that to each other); a
+            # refusal here is an ordinary error the caller can report.
+            free, total = mem_info()
+            if self.nbytes > free - HBM_HEADROOM_BYTES:
+                raise DeviceRuntimeError(f"cannot reserve a HBM arena of {self.nbytes} bytes: {free} of {total} bytes "
+                                         f"are free on this device (all processes counted)")
         self._h = _L().lc_rt_arena_create(self.nbytes, 1 if pinned else 0)
         if not self._h:
             kind = "pinned host" if pinned else "HBM"
