@@ -94,7 +94,8 @@ def strip_flag(argv: Sequence[str], flag: str, has_value: bool = True) -> List[s
     return out
 
 
-def launch_ranks(module: str, argv: Sequence[str], n: int, extra_env: Optional[dict] = None) -> int:
+def launch_ranks(module: str, argv: Sequence[str], n: int, extra_env: Optional[dict] = None,
+                 grace_s: float = 40.0) -> int:
     """Runs ``python -m module *argv`` as ``n`` ranks (rendezvous on 127.0.0.1, RANK / LOCAL_RANK
     / WORLD_SIZE set) and returns the worst exit status. Rank 0 inherits stdin and stdout; the
     others read nothing and write to stderr only. If a rank dies the others are terminated:
@@ -129,8 +130,17 @@ def launch_ranks(module: str, argv: Sequence[str], n: int, extra_env: Optional[d
                         procs[o].terminate()
             time.sleep(0.05)
     except KeyboardInterrupt:
+        # Rank 0 is told first and given time: it finishes what it has admitted (a server drains),
+        # closes the ensemble, and with that lets the other ranks leave their loops on their own.
+        # Only what is still there afterwards is terminated.
+        if 0 in live:
+            procs[0].terminate()
+            deadline = time.time() + grace_s
+            while time.time() < deadline and any(procs[r].poll() is None for r in live):
+                time.sleep(0.05)
         for r in live:
-            procs[r].terminate()
+            if procs[r].poll() is None:
+                procs[r].terminate()
         for r in live:
             try:
                 procs[r].wait(10)

@@ -29,6 +29,8 @@ Routes
 Consensus responses carry an extra ``consensus`` object (votes, rounds, agreement,
 unanimity) next to the OpenAI fields.
 
+SIGTERM drains the server: new requests get 503, the admitted ones are answered, then it exits.
+
 At most ``max_pending`` requests are accepted at a time (answered or not yet): one more gets
 429 with a Retry-After header instead of an unbounded wait behind engines that are already full.
 
@@ -99,6 +101,7 @@ class ConsensusServer:
                                            "cancelled_total": 0, "rejected_total": 0}
         self._lock = threading.Lock()
         self._stop = threading.Event()
+        self._draining = threading.Event()       # set by drain(): refuse new requests, finish the admitted ones
         server = self
 
         class Handler(BaseHTTPRequestHandler):
@@ -126,17 +129,44 @@ class ConsensusServer:
         log.info("serving on http://%s:%d", self.host, self.port)
         return self
 
-    def serve_forever(self) -> None:
+    def serve_forever(self, drain_grace_s: float = 30.0) -> None:
         """Runs the engine driver on the calling thread (GPU contexts stay on the main
-        thread) and the HTTP accept loop on a helper thread."""
+        thread) and the HTTP accept loop on a helper thread. SIGTERM (and a first Ctrl-C) drain
+        the server: new requests are refused with 503, the ones in flight are answered (for at
+        most ``drain_grace_s`` seconds), then the loop ends."""
+        import signal
+
         self._http.start()
         log.info("serving on http://%s:%d", self.host, self.port)
+        old = {}
+        if threading.current_thread() is threading.main_thread():
+            for sig in (signal.SIGTERM, signal.SIGINT):
+                old[sig] = signal.signal(sig, lambda *_: self.drain(drain_grace_s))
         try:
             self._drive()
         except KeyboardInterrupt:
             pass
         finally:
+            for sig, h in old.items():
+                signal.signal(sig, h)
             self.shutdown()
+
+    def drain(self, grace_s: float = 30.0) -> None:
+        """Stops admitting requests and ends the serving loop once the admitted ones are answered
+        (or ``grace_s`` has passed). Returns at once; a second call stops the loop immediately."""
+        if self._draining.is_set():
+            self._stop.set()
+            return
+        self._draining.set()
+        log.info("draining: %d request(s) in flight", self._outstanding)
+
+        def wait():
+            deadline = time.perf_counter() + grace_s
+            while self._outstanding > 0 and time.perf_counter() < deadline and not self._stop.is_set():
+                time.sleep(0.05)
+            self._stop.set()
+
+        threading.Thread(target=wait, daemon=True).start()
 
     def shutdown(self) -> None:
         self._stop.set()
@@ -433,6 +463,8 @@ class ConsensusServer:
                 raise HTTPError(400, f"invalid JSON body: {e}")
             if path not in ("/v1/chat/completions", "/v1/completions", "/v1/embeddings"):
                 raise HTTPError(404, f"no route {path}")
+            if self._draining.is_set():
+                raise HTTPError(503, "the server is shutting down")
             with self._lock:
                 admitted = self._outstanding < self.max_pending
                 if admitted:
@@ -466,7 +498,7 @@ class ConsensusServer:
 
     def _send(self, h, status: int, payload: bytes, ctype: str) -> None:
         h.send_response(status)
-        if status == 429:
+        if status in (429, 503):
             h.send_header("Retry-After", "1")
         h.send_header("Content-Type", ctype)
         h.send_header("Content-Length", str(len(payload)))

@@ -312,3 +312,69 @@ def test_toml_configs_load_with_the_standard_library_parser(monkeypatch):
     monkeypatch.setattr(builtins, "__import__", no_tomli)
     for f in sorted(CONFIGS.glob("*.toml")):
         assert load_config(str(f)).members, f.name
+
+
+def test_sigterm_drains_the_server_admitted_requests_are_answered_new_ones_refused(tmp_path):
+    """`llm-consensus-serve` under SIGTERM: the request in flight gets its 200, a request that
+    arrives during the drain gets 503 with Retry-After, and the process exits by itself."""
+    import json as _json
+    import signal
+    import socket
+    import subprocess
+    import sys
+    import threading
+    import time
+    import urllib.error
+    import urllib.request
+    from pathlib import Path
+
+    root = Path(__file__).resolve().parents[1]
+    cfg = tmp_path / "slow.toml"
+    cfg.write_text('strategy = "majority_vote"\n[sampling]\ntemperature = 0.0\nmax_new_tokens = 300\n'
+                   '[models.default]\npreset = "tiny-llama"\nseed = 1\nkv_blocks = 512\n')
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    import os
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    env.update(PYTHONPATH=str(root), OMP_NUM_THREADS="2")
+    proc = subprocess.Popen([sys.executable, "-m", "llm_consensus_amd.serve.server", "--config", str(cfg), "--device", "cpu",
+                             "--gpus", "1", "--port", str(port)], env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE,
+                            text=True)
+
+    def post(body, timeout=120):
+        req = urllib.request.Request(f"http://127.0.0.1:{port}/v1/completions", _json.dumps(body).encode(),
+                                     {"Content-Type": "application/json"})
+        with urllib.request.urlopen(req, timeout=timeout) as r:
+            return r.status, _json.loads(r.read())
+
+    try:
+        for _ in range(600):
+            try:
+                with urllib.request.urlopen(f"http://127.0.0.1:{port}/health", timeout=2) as r:
+                    if r.status == 200:
+                        break
+            except OSError:
+                assert proc.poll() is None, proc.stderr.read()[-2000:]
+                time.sleep(0.1)
+        got = {}
+        t = threading.Thread(target=lambda: got.update(slow=post({"model": "default", "prompt": "long one", "max_tokens": 300})))
+        t.start()
+        time.sleep(0.5)                              # the slow request is being generated
+        proc.send_signal(signal.SIGTERM)
+        time.sleep(0.3)
+        try:
+            post({"model": "default", "prompt": "late", "max_tokens": 3}, timeout=10)
+            late = 200
+        except urllib.error.HTTPError as e:
+            late = e.code
+            assert e.headers.get("Retry-After") == "1"
+        except OSError:
+            late = "closed"
+        t.join(60)
+        assert got["slow"][0] == 200 and got["slow"][1]["usage"]["completion_tokens"] == 300
+        assert late in (503, "closed")
+        assert proc.wait(30) == 0
+    finally:
+        if proc.poll() is None:
+            proc.kill()
