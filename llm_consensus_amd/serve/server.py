@@ -29,6 +29,7 @@ Routes
 Consensus responses carry an extra ``consensus`` object (votes, rounds, agreement,
 unanimity) next to the OpenAI fields.
 
+With ``--api-key`` (or $CONSENSUS_API_KEY) the POST routes need ``Authorization: Bearer <key>``.
 SIGTERM drains the server: new requests get 503, the admitted ones are answered, then it exits.
 
 At most ``max_pending`` requests are accepted at a time (answered or not yet): one more gets
@@ -43,6 +44,7 @@ over a tensor / expert parallel group run such a request to its end.
 from __future__ import annotations
 
 import json
+import os
 import queue
 import select
 import socket
@@ -84,7 +86,7 @@ class HTTPError(Exception):
 class ConsensusServer:
     def __init__(self, ensemble, host: str = "127.0.0.1", port: int = 8000, max_batch: int = 64,
                  batch_window_ms: float = 5.0, request_timeout_s: float = 600.0, continuous: bool = True,
-                 max_pending: int = 4096) -> None:
+                 max_pending: int = 4096, api_key: Optional[str] = None) -> None:
         self.ensemble = ensemble
         self.continuous = continuous
         self.max_batch, self.window = max_batch, batch_window_ms / 1e3
@@ -93,6 +95,7 @@ class ConsensusServer:
         # Retry-After instead of queueing without bound behind work that already fills the engines.
         self.max_pending = max_pending
         self._outstanding = 0
+        self.api_key = api_key or None           # when set, POST routes need "Authorization: Bearer <key>"
         self.jobs: "queue.Queue[_Job]" = queue.Queue()
         self.cancels: "queue.Queue[_Job]" = queue.Queue()      # jobs whose client disconnected (see _cancel)
         self._cancels_served = False     # only the single-process continuous driver takes work out of engines
@@ -463,6 +466,12 @@ class ConsensusServer:
                 raise HTTPError(400, f"invalid JSON body: {e}")
             if path not in ("/v1/chat/completions", "/v1/completions", "/v1/embeddings"):
                 raise HTTPError(404, f"no route {path}")
+            if self.api_key is not None:
+                import hmac
+
+                given = (h.headers.get("Authorization") or "").removeprefix("Bearer ").strip()
+                if not hmac.compare_digest(given.encode(), self.api_key.encode()):
+                    raise HTTPError(401, "missing or wrong API key (Authorization: Bearer ...)")
             if self._draining.is_set():
                 raise HTTPError(503, "the server is shutting down")
             with self._lock:
@@ -745,6 +754,8 @@ def main(argv: Optional[list] = None) -> int:
     ap.add_argument("--port", type=int, default=8000)
     ap.add_argument("--max-batch", type=int, default=64)
     ap.add_argument("--batch-window-ms", type=float, default=5.0)
+    ap.add_argument("--api-key", default=os.environ.get("CONSENSUS_API_KEY"),
+                    help="require 'Authorization: Bearer <key>' on the POST routes (default: $CONSENSUS_API_KEY, unset = open)")
     ap.add_argument("--request-timeout", type=float, default=600.0,
                     help="seconds a request may take before it is answered 504 and its work is cancelled")
     ap.add_argument("--max-pending", type=int, default=4096,
@@ -794,7 +805,7 @@ def main(argv: Optional[list] = None) -> int:
     try:
         ConsensusServer(ens, args.host, args.port, args.max_batch, args.batch_window_ms,
                         request_timeout_s=args.request_timeout, continuous=not args.batched,
-                        max_pending=args.max_pending).serve_forever()
+                        max_pending=args.max_pending, api_key=args.api_key).serve_forever()
     finally:
         if args.distributed:
             ens.close()

@@ -221,3 +221,23 @@ def test_a_request_that_times_out_is_answered_504_and_cancelled():
         assert st["requests.cancelled"] == 1 and st["sched.running"] == 0 and st["decode.tokens"] < 400
     finally:
         srv.shutdown()
+
+
+def test_api_key_guards_the_post_routes(server):
+    import urllib.error
+
+    srv, ens = server
+    srv.api_key = "s3cret"
+    try:
+        body = {"model": next(iter(ens.backends)), "prompt": "hi", "max_tokens": 2}
+        with pytest.raises(urllib.error.HTTPError) as e1:
+            _post(srv.port, "/v1/completions", body)
+        assert e1.value.code == 401
+        req = urllib.request.Request(f"http://127.0.0.1:{srv.port}/v1/completions", json.dumps(body).encode(),
+                                     {"Content-Type": "application/json", "Authorization": "Bearer s3cret"})
+        with urllib.request.urlopen(req, timeout=120) as r:
+            assert r.status == 200
+        with urllib.request.urlopen(f"http://127.0.0.1:{srv.port}/health", timeout=5) as r:
+            assert r.status == 200            # liveness stays open
+    finally:
+        srv.api_key = None
