@@ -119,7 +119,18 @@ class ConsensusServer:
             def do_POST(self):
                 server._dispatch(self, "POST")
 
-        self.httpd = ThreadingHTTPServer((host, port), Handler)
+        class Server(ThreadingHTTPServer):
+            def handle_error(self, request, client_address):
+                # a client that resets its connection is not a server error worth a traceback
+                import sys
+
+                e = sys.exc_info()[1]
+                if isinstance(e, (ConnectionResetError, BrokenPipeError, TimeoutError)):
+                    log.debug("client %s went away: %s", client_address, e)
+                else:
+                    super().handle_error(request, client_address)
+
+        self.httpd = Server((host, port), Handler)
         self.httpd.daemon_threads = True
         self.host, self.port = self.httpd.server_address[:2]
         self._driver = threading.Thread(target=self._drive, name="consensus-driver", daemon=True)
