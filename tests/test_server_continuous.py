@@ -241,3 +241,83 @@ def test_api_key_guards_the_post_routes(server):
             assert r.status == 200            # liveness stays open
     finally:
         srv.api_key = None
+
+
+def test_soak_with_clients_that_hang_up_at_random_leaves_nothing_behind():
+    """Eight clients for six seconds: consensus questions, direct completions and token streams,
+    four in ten abandoned at a random moment. Afterwards nothing is in flight, nothing runs or
+    waits in the engine, every KV block is free or kept by the prefix cache, and the server answers."""
+    import random
+    import socket
+
+    cfg = config_from_dict({"strategy": "majority_vote", "seed": 3, "sampling": {"temperature": 0.7, "max_new_tokens": 30},
+                            "models": {"default": {"preset": "tiny-llama", "seed": 1, "kv_blocks": 1024}}})
+    ens = build_ensemble(cfg)
+    srv = ConsensusServer(ens, port=0, max_batch=8, max_pending=64).start()
+    eng = next(iter(ens.backends.values())).engine
+    model = next(iter(ens.backends))
+    stop = time.time() + 6.0
+    counts = {"ok": 0, "hung_up": 0, "other": 0}
+    lock = threading.Lock()
+
+    def raw(path, body):
+        s = socket.create_connection(("127.0.0.1", srv.port), timeout=60)
+        data = json.dumps(body).encode()
+        s.sendall(f"POST {path} HTTP/1.1\r\nHost: x\r\nContent-Type: application/json\r\n"
+                  f"Content-Length: {len(data)}\r\n\r\n".encode() + data)
+        return s
+
+    def client(seed):
+        rng = random.Random(seed)
+        while time.time() < stop:
+            kind = rng.choice(["consensus", "direct", "stream"])
+            if kind == "consensus":
+                path, body = "/v1/chat/completions", {"messages": [{"role": "user", "content": f"q{rng.random()} A) a B) b C) c D) d"}]}
+            else:
+                path, body = "/v1/completions", {"model": model, "prompt": f"p{rng.random()}",
+                                                 "max_tokens": rng.choice([5, 20, 30]), "stream": kind == "stream"}
+            try:
+                s = raw(path, body)
+                if rng.random() < 0.4:
+                    time.sleep(rng.random() * 0.2)
+                    s.close()
+                    with lock:
+                        counts["hung_up"] += 1
+                    continue
+                buf = b""
+                while True:
+                    chunk = s.recv(65536)
+                    if not chunk:
+                        break
+                    buf += chunk
+                    if kind == "stream":
+                        if b"[DONE]" in buf:
+                            break
+                    elif b"\r\n\r\n" in buf:
+                        head, rest = buf.split(b"\r\n\r\n", 1)
+                        cl = [l for l in head.split(b"\r\n") if l.lower().startswith(b"content-length")]
+                        if cl and len(rest) >= int(cl[0].split(b":")[1]):
+                            break
+                s.close()
+                with lock:
+                    counts["ok" if buf.split(b" ", 2)[1:2] == [b"200"] else "other"] += 1
+            except OSError:
+                with lock:
+                    counts["other"] += 1
+
+    try:
+        ths = [threading.Thread(target=client, args=(i,)) for i in range(8)]
+        [t.start() for t in ths]
+        [t.join(120) for t in ths]
+        deadline = time.time() + 20
+        while time.time() < deadline and (srv._outstanding or eng.stats()["sched.running"] or eng.stats()["sched.waiting"]):
+            time.sleep(0.05)
+        st = eng.stats()
+        assert counts["ok"] > 10 and counts["hung_up"] > 5 and counts["other"] == 0, counts
+        assert srv._outstanding == 0 and st["sched.running"] == 0 and st["sched.waiting"] == 0
+        assert st["kv.blocks_free"] + st["kv.blocks_cached"] == st["kv.blocks_total"]
+        assert st.get("requests.cancelled", 0) > 0 and srv.counters["cancelled_total"] > 0
+        code, out = _post(srv.port, "/v1/completions", {"model": model, "prompt": "still there?", "max_tokens": 3})
+        assert code == 200 and out["usage"]["completion_tokens"] == 3
+    finally:
+        srv.shutdown()
