@@ -31,6 +31,7 @@ class GenParams:
     n: int = 1                                  # chains forked from the prompt
     decision_targets: Optional[List[str]] = None  # if set, also return log-probs of these continuations
     #                                               at the position after the generated text
+    stop: Optional[List[str]] = None            # text-level stop sequences: a chain ends before the first of them
 
 
 @dataclass
@@ -41,6 +42,7 @@ class GenResult:
     decision_logprobs: Optional[List[List[float]]] = None  # [chain][target]
     prompt_tokens: int = 0
     cached_tokens: int = 0
+    finish_reasons: List[str] = field(default_factory=list)   # per chain: "stop" (stop token / sequence) or "length"
 
 
 class Handle:
@@ -130,6 +132,12 @@ class Backend:
     def fail_pending(self, err: BaseException) -> None:
         """Completes every outstanding handle with ``err`` (used by drivers that step this
         backend's engines themselves and caught a failure)."""
+
+    def has_leftovers(self) -> bool:
+        """True while the backend still has to let go of work nobody waits for any more (cancelled
+        requests that leave at the engine's next step): a driver that is otherwise idle keeps
+        stepping until this is False."""
+        return False
 
     def cancel(self, handle: Handle) -> bool:
         """Stops work on one submitted request, where a backend can (the reference cannot: a call

@@ -29,6 +29,9 @@ class EngineBackend(Backend):
         self.chat_format = chat_format
         self._pending: Dict[int, tuple] = {}
         self._streams: Dict[int, list] = {}
+        self._stops: Dict[int, List[str]] = {}      # text-level stop sequences of pending requests
+        self._discard: set = set()                  # requests finished early here whose engine result is to be dropped
+        self._stop_plen: Dict[int, int] = {}        # prompt lengths of requests with stop sequences (for their usage record)
 
     def _params(self, p: GenParams) -> "core.SamplingParams":
         sp = core.SamplingParams()
@@ -52,6 +55,9 @@ class EngineBackend(Backend):
             rid = self.engine.submit(ids, core.RequestKind.Generate, max(1, params.n), self._params(params), dec)
             self._pending[rid] = ("gen", h)
             h.backend = self
+            if params.stop:
+                self._stops[rid] = [t for t in params.stop if t]
+                self._stop_plen[rid] = len(ids)
             if on_text is not None:
                 self._streams[rid] = [on_text, [""] * max(1, params.n)]   # callback, text already sent per chain
         except Exception as e:  # a bad request fails that member only
@@ -115,16 +121,19 @@ class EngineBackend(Backend):
             self._group_failure(e)
             return False
         self._harvest(final=not self.engine.has_work())
-        return bool(self._pending)
+        return bool(self._pending or self._discard)
 
     def harvest(self) -> bool:
         """Completes the handles of requests the engine has finished (for drivers that step
         the engine themselves). Returns True while requests remain."""
         self._harvest(final=not self.engine.has_work())
-        return bool(self._pending)
+        return bool(self._pending or self._discard)
 
     def fail_pending(self, err: BaseException) -> None:
         self._fail_all(err)
+
+    def has_leftovers(self) -> bool:
+        return bool(self._discard or self.engine._cancel)
 
     def cancel(self, handle: Handle) -> bool:
         """The engine drops the request at its next step boundary (waiting, prefilling or
@@ -136,6 +145,7 @@ class EngineBackend(Backend):
         for rid, (_, h) in self._pending.items():
             if h is handle:
                 self._streams.pop(rid, None)
+                self._stops.pop(rid, None)
                 return self.engine.cancel(rid)
         return False
 
@@ -151,6 +161,8 @@ class EngineBackend(Backend):
                 h.set_error(BackendError(f"engine failure: {type(e).__name__}: {e}"))
         self._pending.clear()
         self._streams.clear()
+        self._stops.clear()
+        self._discard.clear()
         try:
             self.engine.abort_all()
         except Exception as e2:  # noqa: BLE001
@@ -171,6 +183,15 @@ class EngineBackend(Backend):
             text = self.tok.decode(toks)
             if not final and text.endswith("\ufffd"):
                 text = text[:-1]            # an unfinished sequence decodes to ONE replacement character
+            stops = self._stops.get(rid)
+            if stops:
+                # nothing of a stop sequence, or after it, may reach the client: cut at the first one,
+                # and while the chain runs hold back a tail that could still grow into one
+                cut = self._first_stop(text, stops)
+                if cut >= 0:
+                    text = text[:cut]
+                elif not final:
+                    text = text[:max(0, len(text) - (max(len(t) for t in stops) - 1))]
             if len(text) > len(sent[i]) and text.startswith(sent[i]):
                 cb(i, text[len(sent[i]):])
                 sent[i] = text
@@ -183,7 +204,56 @@ class EngineBackend(Backend):
                 cb(i, self.RESTART_MARKER + text)
                 sent[i] = text
 
+    @staticmethod
+    def _first_stop(text: str, stops: Sequence[str]) -> int:
+        at = [i for i in (text.find(t) for t in stops) if i >= 0]
+        return min(at) if at else -1
+
+    def _texts(self, token_lists) -> List[str]:
+        eos = self.tok.eos_id
+        out = []
+        for toks in token_lists:
+            if eos is not None and toks and toks[-1] == eos:
+                toks = toks[:-1]
+            out.append(self.tok.decode(toks))
+        return out
+
+    def _stop_early(self) -> None:
+        """Requests with text-level stop sequences: once EVERY chain of a request has produced one, the
+        request is finished here with the truncated texts and the engine is told to drop it (its
+        blocks return at the next step; its Aborted result is discarded when it comes)."""
+        for rid, stops in list(self._stops.items()):
+            ent = self._pending.get(rid)
+            if ent is None:
+                self._stops.pop(rid, None)
+                continue
+            chains = self.engine.sched.tokens_so_far(rid)
+            if not chains or not all(chains):
+                continue
+            texts = self._texts(chains)
+            cuts = [self._first_stop(t, stops) for t in texts]
+            if any(c < 0 for c in cuts):
+                continue
+            if rid in self._streams:
+                self._emit(rid, chains, final=True)
+                del self._streams[rid]
+            kind, h = ent
+            plen = self._stop_plen.pop(rid, 0)
+            h.usage = (plen, sum(len(t) for t in chains), 0)
+            h.set_result(GenResult(texts=[t[:c] for t, c in zip(texts, cuts)], token_ids=[list(t) for t in chains],
+                                   cum_logprobs=[0.0] * len(chains), prompt_tokens=plen,
+                                   finish_reasons=["stop"] * len(chains)))
+            del self._pending[rid]
+            del self._stops[rid]
+            if self.engine.cancel(rid):
+                self._discard.add(rid)
+
     def _harvest(self, final: bool) -> None:
+        if self._stops:
+            self._stop_early()
+        for rid in list(self._discard):
+            if self.engine.pop_result(rid) is not None or rid not in self.engine._reqs:
+                self._discard.discard(rid)
         for rid in list(self._streams):
             if rid in self._pending:
                 chains = self.engine.sched.tokens_so_far(rid)
@@ -206,22 +276,25 @@ class EngineBackend(Backend):
                 self._emit(rid, out.token_ids, final=True)
                 del self._streams[rid]
             if kind == "gen":
-                eos = self.tok.eos_id
-                texts = []
-                for toks in out.token_ids:
-                    if eos is not None and toks and toks[-1] == eos:
-                        toks = toks[:-1]
-                    texts.append(self.tok.decode(toks))
+                texts = self._texts(out.token_ids)
+                reasons = ["length" if r == "Length" else "stop" for r in out.finish_reasons]
+                stops = self._stops.pop(rid, None)
+                self._stop_plen.pop(rid, None)
+                if stops:       # a chain that ran on (the others had not stopped yet) still ends at its stop sequence
+                    for i, t in enumerate(texts):
+                        cut = self._first_stop(t, stops)
+                        if cut >= 0:
+                            texts[i], reasons[i] = t[:cut], "stop"
                 h.set_result(GenResult(texts=texts, token_ids=out.token_ids, cum_logprobs=out.cum_logprobs,
                                        decision_logprobs=out.decision_logprobs, prompt_tokens=out.prompt_len,
-                                       cached_tokens=out.cached_tokens), at=out.finished_at)
+                                       cached_tokens=out.cached_tokens, finish_reasons=reasons), at=out.finished_at)
             elif kind == "score":
                 h.set_result(out.scores, at=out.finished_at)
             else:
                 h.set_result(out.embedding, at=out.finished_at)
 
     def engines(self) -> list:
-        return [self.engine] if self._pending else []
+        return [self.engine] if (self._pending or self.has_leftovers()) else []
 
     def warm_up(self, **kw) -> Dict[str, float]:
         """See Engine.warm_up (first-use costs paid before the first request)."""

@@ -20,7 +20,7 @@ Routes
     POST /v1/chat/completions    model "consensus" (default) runs the configured strategy on
                                  the last user message; any other model name is served by
                                  that member model directly (n, max_tokens, temperature,
-                                 top_p, seed honoured). ``stream: true`` yields SSE chunks: one
+                                 top_p, seed, stop honoured; finish_reason is "stop" or "length"). ``stream: true`` yields SSE chunks: one
                                  per engine step for member models (tokens as they are
                                  sampled), one for a consensus answer (it does not exist
                                  before the vote is in).
@@ -231,7 +231,8 @@ class ConsensusServer:
         tickets: Dict[int, _Job] = {}
         direct: List[tuple] = []
         while not self._stop.is_set():
-            idle = not tickets and not direct
+            # (an engine that still holds a cancelled request is not idle: it lets go at its next step)
+            idle = not tickets and not direct and not any(b.has_leftovers() for b in stepper.backends)
             try:
                 new = [self.jobs.get(timeout=0.05)] if idle else []
             except queue.Empty:
@@ -281,7 +282,7 @@ class ConsensusServer:
                 # direct requests are advanced here, through the same stepper.
                 # ... and so are the leftovers of cancelled requests: an engine lets them go at its
                 # next step boundary, which has to come even if nobody else waits for that engine.
-                leftovers = not was_active and not direct and any(b.engines() for b in stepper.backends)
+                leftovers = not was_active and not direct and any(b.has_leftovers() for b in stepper.backends)
                 if not was_active and (direct or leftovers):
                     if not stepper.step():
                         time.sleep(20e-6)
@@ -552,8 +553,15 @@ class ConsensusServer:
     def _gen_params(self, body: Dict[str, Any]) -> GenParams:
         s = self.ensemble.config.sampling
         mt = body.get("max_completion_tokens", body.get("max_tokens"))
+        stop = body.get("stop")
+        if isinstance(stop, str):
+            stop = [stop]
+        if stop is not None and (not isinstance(stop, list) or len(stop) > 4
+                                 or not all(isinstance(t, str) and t for t in stop)):
+            raise HTTPError(400, "'stop' must be a non-empty string or a list of up to 4 of them")
         try:
             return GenParams(
+                stop=stop or None,
                 temperature=float(body.get("temperature", s.temperature)),
                 top_p=float(body.get("top_p", s.top_p)),
                 top_k=int(body.get("top_k", s.top_k)),
@@ -628,14 +636,16 @@ class ConsensusServer:
             usage = {"prompt_tokens": g.prompt_tokens, "completion_tokens": ct,
                      "total_tokens": g.prompt_tokens + ct,
                      "prompt_tokens_details": {"cached_tokens": g.cached_tokens}}
+        fr = list(getattr(job.result, "finish_reasons", None) or [])
+        reasons = [fr[i] if i < len(fr) else "stop" for i in range(len(texts))]
         if body.get("stream"):
             return self._stream(h, rid, created, model, texts, chat, extra)
         if chat:
-            choices = [{"index": i, "message": {"role": "assistant", "content": t}, "finish_reason": "stop"}
+            choices = [{"index": i, "message": {"role": "assistant", "content": t}, "finish_reason": reasons[i]}
                        for i, t in enumerate(texts)]
             obj = "chat.completion"
         else:
-            choices = [{"index": i, "text": t, "finish_reason": "stop", "logprobs": None} for i, t in enumerate(texts)]
+            choices = [{"index": i, "text": t, "finish_reason": reasons[i], "logprobs": None} for i, t in enumerate(texts)]
             obj = "text_completion"
         self._send_json(h, 200, {"id": rid, "object": obj, "created": created, "model": model,
                                  "choices": choices, "usage": usage, **extra})
@@ -695,10 +705,12 @@ class ConsensusServer:
             g = job.result
             ct = sum(len(t) for t in g.token_ids)
             usage = {"prompt_tokens": g.prompt_tokens, "completion_tokens": ct, "total_tokens": g.prompt_tokens + ct}
+            fr = list(getattr(g, "finish_reasons", None) or [])
             for i in range(len(g.texts)):
                 last = {"usage": usage} if i == len(g.texts) - 1 else {}
-                emit({"index": i, "delta": {}, "finish_reason": "stop"} if chat
-                     else {"index": i, "text": "", "finish_reason": "stop"}, **last)
+                why = fr[i] if i < len(fr) else "stop"
+                emit({"index": i, "delta": {}, "finish_reason": why} if chat
+                     else {"index": i, "text": "", "finish_reason": why}, **last)
         h.wfile.write(b"data: [DONE]\n\n")
         h.wfile.flush()
         h.close_connection = True

@@ -187,7 +187,8 @@ def test_http_member_model_completion_and_stream(server):
     assert events[-1] == "[DONE]"
     chunks = [json.loads(e) for e in events[:-1]]
     assert chunks[0]["choices"][0]["delta"]["role"] == "assistant"
-    assert chunks[-1]["choices"][0]["finish_reason"] == "stop" and chunks[-1]["usage"]["completion_tokens"] == 4
+    # the whole budget was used: "length" (a stop token or stop sequence would say "stop")
+    assert chunks[-1]["choices"][0]["finish_reason"] == "length" and chunks[-1]["usage"]["completion_tokens"] == 4
     # tokens leave as they are sampled: several content chunks, and together they are the completion
     pieces = [c["choices"][0]["delta"].get("content", "") for c in chunks if c["choices"][0]["finish_reason"] is None]
     assert len(pieces) >= 2
@@ -197,7 +198,7 @@ def test_http_member_model_completion_and_stream(server):
     # text-completion flavour of the same stream
     st, raw = _post(server.port, "/v1/completions", {"model": "m1", "prompt": "hello", "max_tokens": 3, "stream": True})
     ev = [json.loads(l[6:]) for l in raw.decode().splitlines() if l.startswith("data: ") and l != "data: [DONE]"]
-    assert ev[-1]["choices"][0]["finish_reason"] == "stop" and len(ev) >= 2
+    assert ev[-1]["choices"][0]["finish_reason"] == "length" and len(ev) >= 2
 
 
 def test_consensus_responses_report_token_usage(server, tiny_ensemble):

@@ -3,6 +3,7 @@ admitted at different times share the engine, each answered as soon as it is don
 import json
 import threading
 import time
+import urllib.error
 import urllib.request
 
 import pytest
@@ -102,6 +103,7 @@ def test_streamed_text_that_diverges_after_a_preemption_is_restarted_not_silence
 
     be = EngineBackend.__new__(EngineBackend)
     be.tok = ByteLevelTokenizer()
+    be._stops = {}
     got = []
     be._streams = {7: [lambda chain, text: got.append((chain, text)), [""]]}
     enc = lambda s: list(be.tok.encode(s, add_bos=False))  # noqa: E731
@@ -321,3 +323,43 @@ def test_soak_with_clients_that_hang_up_at_random_leaves_nothing_behind():
         assert code == 200 and out["usage"]["completion_tokens"] == 3
     finally:
         srv.shutdown()
+
+
+def test_stop_sequences_end_a_completion_early_and_finish_reasons_are_reported(server):
+    """``stop``: the text ends before the first stop sequence, the engine stops generating for the
+    request (far fewer tokens than max_tokens), streamed chunks never contain the sequence or
+    anything after it; without a stop sequence a completion that uses its whole budget says "length"."""
+    srv, ens = server
+    model = next(iter(ens.backends))
+    code, full = _post(srv.port, "/v1/completions", {"model": model, "prompt": "count for me", "max_tokens": 40, "temperature": 0.0})
+    text = full["choices"][0]["text"]
+    assert code == 200 and full["choices"][0]["finish_reason"] == "length" and full["usage"]["completion_tokens"] == 40
+    assert len(text) > 12
+    stop = text[8:11]                                 # three characters the model will produce again (greedy)
+    cut = text.find(stop)
+    code, out = _post(srv.port, "/v1/completions", {"model": model, "prompt": "count for me", "max_tokens": 40,
+                                                    "temperature": 0.0, "stop": stop})
+    assert code == 200 and out["choices"][0]["text"] == text[:cut] and out["choices"][0]["finish_reason"] == "stop"
+    assert out["usage"]["completion_tokens"] < 40 and out["usage"]["prompt_tokens"] == full["usage"]["prompt_tokens"]
+    # streamed: the pieces add up to the same truncated text
+    req = urllib.request.Request(f"http://127.0.0.1:{srv.port}/v1/completions",
+                                 json.dumps({"model": model, "prompt": "count for me", "max_tokens": 40, "temperature": 0.0,
+                                             "stop": [stop, "\\u0000never"], "stream": True}).encode(),
+                                 {"Content-Type": "application/json"})
+    pieces, reasons = [], []
+    with urllib.request.urlopen(req, timeout=120) as r:
+        for line in r.read().decode().splitlines():
+            if line.startswith("data: {"):
+                c = json.loads(line[6:])["choices"][0]
+                pieces.append(c.get("text", ""))
+                if c.get("finish_reason"):
+                    reasons.append(c["finish_reason"])
+    assert "".join(pieces) == text[:cut] and reasons == ["stop"]
+    with pytest.raises(urllib.error.HTTPError) as bad:
+        _post(srv.port, "/v1/completions", {"model": model, "prompt": "x", "stop": ["a", "b", "c", "d", "e"]})
+    assert bad.value.code == 400
+    eng = ens.backends[model].engine
+    deadline = time.time() + 20
+    while time.time() < deadline and (eng.stats()["sched.running"] or ens.backends[model]._discard):
+        time.sleep(0.05)
+    assert eng.stats()["sched.running"] == 0 and not ens.backends[model]._discard
