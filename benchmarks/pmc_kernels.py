@@ -34,7 +34,9 @@ def run():
     w_dn = ops.LinearWeight.from_dense(rnd(4096, 14336), None, dev)
     x8k, x256, x64 = rnd(8192, K, scale=0.5), rnd(256, K, scale=0.5), rnd(64, K, scale=0.5)
     a64 = rnd(64, 14336, scale=0.5)
+    a8k = rnd(8192, 14336, scale=0.5)
     for _ in range(3):
+        ops.linear(a8k, w_dn)          # gemm256w (four waves, K >= 8192)
         ops.linear(x8k, w_gu)          # gemm256 (SwiGLU epilogue)
         ops.linear(x8k, w_o)           # gemm256
         ops.linear(x256, w_gu)         # gemm_panel, 256-row panel
