@@ -332,8 +332,10 @@ def test_warm_up_records_every_configured_decode_graph_before_the_first_request(
 
     first = ask(3, 12)
     assert eng.stats().get("decode.graph_captures", 0) == before       # nothing was recorded while serving
-    steady = min(ask(3, 12) for _ in range(3))
-    assert first < 1.5 * steady + 0.02, (first, steady)
+    # the capture counter above is the invariant; the clock only has to show that nothing of the size of
+    # a recording (hundreds of ms for these graphs) happened, with room for a busy host
+    steady = sorted(ask(3, 12) for _ in range(3))[1]
+    assert first < 1.5 * steady + 0.05, (first, steady)
     ask(7, 5)
     ask(1, 20)
     assert eng.stats().get("decode.graph_captures", 0) == before
