@@ -26,6 +26,12 @@ Routes
                                  before the vote is in).
     POST /v1/completions         same for a raw prompt
     POST /v1/embeddings          pooled, L2-normalised embeddings from a member model
+    POST /v1/score               extension: ``{"model", "prompt", "targets": [..]}`` -> the log-probability
+                                 of each target continuation (its first token) after the prompt; with
+                                 ``decision_targets`` on /v1/completions every choice carries the same for
+                                 the position after its reply (``decision_logprobs``): the constrained
+                                 decisions the strategies take (verdict words, choice letters), for callers
+                                 that run their own voting
 Consensus responses carry an extra ``consensus`` object (votes, rounds, agreement,
 unanimity) next to the OpenAI fields.
 
@@ -64,10 +70,11 @@ CONSENSUS_MODEL = "consensus"
 
 @dataclass
 class _Job:
-    kind: str                      # consensus | generate | embed
+    kind: str                      # consensus | generate | embed | score
     model: str
     text: str
     params: Optional[GenParams] = None
+    targets: Optional[List[str]] = None      # score jobs: the continuations to score
     done: threading.Event = field(default_factory=threading.Event)
     # streaming requests: (chain, text) pieces as the engine produces them, None when finished
     chunks: Optional["queue.Queue"] = None
@@ -270,8 +277,7 @@ class ConsensusServer:
                         tickets[pool.submit(j.text)] = j
                     else:
                         be = self.ensemble.backends[j.model]
-                        direct.append((be.submit_embed(j.text) if j.kind == "embed"
-                                       else be.submit_generate(j.text, j.params, self._on_text(j)), j))
+                        direct.append((self._submit_direct(be, j), j))
                 except Exception as e:  # noqa: BLE001
                     j.error = f"{type(e).__name__}: {e}"
                     self._finish(j)
@@ -311,6 +317,14 @@ class ConsensusServer:
                     j.error = str(e)
                 self._finish(j)
             direct = still
+
+    def _submit_direct(self, be, j: _Job):
+        """A request addressed to one member model goes straight to its backend."""
+        if j.kind == "embed":
+            return be.submit_embed(j.text)
+        if j.kind == "score":
+            return be.submit_score(j.text, j.targets)
+        return be.submit_generate(j.text, j.params, self._on_text(j))
 
     @staticmethod
     def _on_text(j: _Job):
@@ -398,9 +412,7 @@ class ConsensusServer:
         direct = [j for j in batch if j.kind != "consensus"]
         handles = []
         for j in direct:
-            be = self.ensemble.backends[j.model]
-            handles.append(be.submit_embed(j.text) if j.kind == "embed"
-                           else be.submit_generate(j.text, j.params, self._on_text(j)))
+            handles.append(self._submit_direct(self.ensemble.backends[j.model], j))
         streaming = any(j.chunks is not None for j in direct)
         for name in {j.model for j in direct}:
             be = self.ensemble.backends[name]
@@ -476,7 +488,7 @@ class ConsensusServer:
                 body = json.loads(h.rfile.read(n) or b"{}")
             except json.JSONDecodeError as e:
                 raise HTTPError(400, f"invalid JSON body: {e}")
-            if path not in ("/v1/chat/completions", "/v1/completions", "/v1/embeddings"):
+            if path not in ("/v1/chat/completions", "/v1/completions", "/v1/embeddings", "/v1/score"):
                 raise HTTPError(404, f"no route {path}")
             if self.api_key is not None:
                 import hmac
@@ -499,6 +511,8 @@ class ConsensusServer:
                     return self._completion(h, body, chat=True)
                 if path == "/v1/completions":
                     return self._completion(h, body, chat=False)
+                if path == "/v1/score":
+                    return self._score(h, body)
                 return self._embeddings(h, body)
             finally:
                 with self._lock:
@@ -559,8 +573,13 @@ class ConsensusServer:
         if stop is not None and (not isinstance(stop, list) or len(stop) > 4
                                  or not all(isinstance(t, str) and t for t in stop)):
             raise HTTPError(400, "'stop' must be a non-empty string or a list of up to 4 of them")
+        dt = body.get("decision_targets")
+        if dt is not None and (not isinstance(dt, list) or not dt or len(dt) > 64
+                               or not all(isinstance(t, str) and t for t in dt)):
+            raise HTTPError(400, "'decision_targets' must be a list of 1-64 non-empty strings")
         try:
             return GenParams(
+                decision_targets=dt,
                 stop=stop or None,
                 temperature=float(body.get("temperature", s.temperature)),
                 top_p=float(body.get("top_p", s.top_p)),
@@ -615,6 +634,8 @@ class ConsensusServer:
                                      f"{model}'s context of {limit} tokens")
         rid = ("chatcmpl-" if chat else "cmpl-") + uuid.uuid4().hex[:24]
         created = int(time.time())
+        if params.decision_targets and (consensus or body.get("stream")):
+            raise HTTPError(400, "'decision_targets' goes with a member model and a whole (not streamed) reply")
         if body.get("stream") and not consensus:
             return self._stream_tokens(h, rid, created, model, text, params, chat)
         job = self.submit(_Job("consensus" if consensus else "generate", model, text, params), h.connection)
@@ -636,8 +657,11 @@ class ConsensusServer:
             usage = {"prompt_tokens": g.prompt_tokens, "completion_tokens": ct,
                      "total_tokens": g.prompt_tokens + ct,
                      "prompt_tokens_details": {"cached_tokens": g.cached_tokens}}
+            if g.decision_logprobs:
+                extra["_decision"] = g.decision_logprobs
         fr = list(getattr(job.result, "finish_reasons", None) or [])
         reasons = [fr[i] if i < len(fr) else "stop" for i in range(len(texts))]
+        decision = extra.pop("_decision", None)
         if body.get("stream"):
             return self._stream(h, rid, created, model, texts, chat, extra)
         if chat:
@@ -647,6 +671,9 @@ class ConsensusServer:
         else:
             choices = [{"index": i, "text": t, "finish_reason": reasons[i], "logprobs": None} for i, t in enumerate(texts)]
             obj = "text_completion"
+        if decision:
+            for c, d in zip(choices, decision):
+                c["decision_logprobs"] = [float(x) for x in d]
         self._send_json(h, 200, {"id": rid, "object": obj, "created": created, "model": model,
                                  "choices": choices, "usage": usage, **extra})
 
@@ -738,6 +765,23 @@ class ConsensusServer:
         h.wfile.write(b"data: [DONE]\n\n")
         h.wfile.flush()
         h.close_connection = True
+
+    def _score(self, h, body: Dict[str, Any]) -> None:
+        """Log-probability of each target's first token after the prompt, from one member model: the
+        constrained decision the strategies take on the device (verdict words, choice letters,
+        /root/reference/src/main.rs:144-148 parses them out of free text instead)."""
+        model = body.get("model")
+        if model not in self.ensemble.backends:
+            raise HTTPError(404, f"unknown model {model!r}")
+        prompt, targets = body.get("prompt"), body.get("targets")
+        if not isinstance(prompt, str) or not prompt:
+            raise HTTPError(400, "'prompt' must be a non-empty string")
+        if (not isinstance(targets, list) or not targets or len(targets) > 64
+                or not all(isinstance(t, str) and t for t in targets)):
+            raise HTTPError(400, "'targets' must be a list of 1-64 non-empty strings")
+        job = self.submit(_Job("score", model, prompt, targets=list(targets)), h.connection)
+        self._send_json(h, 200, {"object": "score", "model": model, "targets": targets,
+                                 "logprobs": [float(x) for x in job.result]})
 
     def _embeddings(self, h, body: Dict[str, Any]) -> None:
         model = body.get("model")

@@ -363,3 +363,44 @@ def test_stop_sequences_end_a_completion_early_and_finish_reasons_are_reported(s
     while time.time() < deadline and (eng.stats()["sched.running"] or ens.backends[model]._discard):
         time.sleep(0.05)
     assert eng.stats()["sched.running"] == 0 and not ens.backends[model]._discard
+
+
+def test_score_route_and_decision_targets_agree_with_the_backend(server):
+    """``POST /v1/score`` returns what ``Backend.submit_score`` returns for the same prompt and
+    targets; ``decision_targets`` on a completion attaches the log-probabilities of the targets at
+    the position after each choice's reply; both reject malformed requests with 400 / 404."""
+    srv, ens = server
+    model = next(iter(ens.backends))
+    targets = [" Good", " NeedsRefinement", " A"]
+    code, out = _post(srv.port, "/v1/score", {"model": model, "prompt": "Is this fine?\n", "targets": targets})
+    assert code == 200 and out["object"] == "score" and out["targets"] == targets and len(out["logprobs"]) == 3
+    assert all(lp <= 0.0 for lp in out["logprobs"])
+    # the same call once more gives the same numbers (greedy scoring has no randomness) ...
+    code, again = _post(srv.port, "/v1/score", {"model": model, "prompt": "Is this fine?\n", "targets": targets})
+    assert again["logprobs"] == pytest.approx(out["logprobs"], abs=1e-5)
+    # ... and a different prompt does not
+    code, other = _post(srv.port, "/v1/score", {"model": model, "prompt": "Something else entirely", "targets": targets})
+    assert other["logprobs"] != pytest.approx(out["logprobs"], abs=1e-5)
+
+    code, gen = _post(srv.port, "/v1/completions", {"model": model, "prompt": "pick one", "max_tokens": 5, "n": 2,
+                                                    "temperature": 0.7, "seed": 5, "decision_targets": [" A", " B"]})
+    assert code == 200 and len(gen["choices"]) == 2
+    for c in gen["choices"]:
+        assert len(c["decision_logprobs"]) == 2 and all(lp <= 0.0 for lp in c["decision_logprobs"])
+    # (the decision is taken on the reply's TOKENS; re-scoring prompt + reply text would re-tokenise
+    # a random-init model's bytes differently, so there is no exact cross-check through the text)
+    code, plain = _post(srv.port, "/v1/completions", {"model": model, "prompt": "pick one", "max_tokens": 5})
+    assert "decision_logprobs" not in plain["choices"][0]
+
+    for path, body, want in (
+        ("/v1/score", {"model": "nobody", "prompt": "x", "targets": ["a"]}, 404),
+        ("/v1/score", {"model": model, "prompt": "", "targets": ["a"]}, 400),
+        ("/v1/score", {"model": model, "prompt": "x", "targets": []}, 400),
+        ("/v1/score", {"model": model, "prompt": "x", "targets": "a"}, 400),
+        ("/v1/completions", {"model": model, "prompt": "x", "decision_targets": [""]}, 400),
+        ("/v1/completions", {"model": model, "prompt": "x", "decision_targets": [" A"], "stream": True}, 400),
+        ("/v1/chat/completions", {"messages": [{"role": "user", "content": "q"}], "decision_targets": [" A"]}, 400),
+    ):
+        with pytest.raises(urllib.error.HTTPError) as bad:
+            _post(srv.port, path, body)
+        assert bad.value.code == want, (path, body)
