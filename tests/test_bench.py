@@ -245,3 +245,22 @@ def test_two_ranks_serve_the_sharded_workloads_in_lock_step_rounds_on_one_gpu():
         sq = out[key]["standing_queue"]
         assert sq["value"] > 0 and "lock-step" in sq["mode"] and sq["questions"] == 16, (key, sq)
         assert coll(out[key]).startswith("p2p"), out[key]
+
+
+def test_http_load_benchmark_runs_a_closed_loop_through_the_server():
+    """benchmarks/http_load.py: the vote ensemble behind the HTTP server, a separate client process
+    keeping 6 connections busy; every counted question is answered, none fails."""
+    import json
+    import subprocess
+    import sys
+    from pathlib import Path
+
+    root = Path(__file__).resolve().parents[1]
+    p = subprocess.run([sys.executable, str(root / "benchmarks" / "http_load.py"), "--device", "cpu", "--models",
+                        "tiny-llama,tiny-llama", "--in-flight", "6", "--questions", "12", "--prompt-len", "96",
+                        "--new-tokens", "3"], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-2000:]
+    out = json.loads(p.stdout.strip().splitlines()[-1])
+    assert out["answers"] == 12 and out["errors"] == 0 and out["answers_per_s"] > 0
+    assert out["p99_latency_ms"] >= out["p95_latency_ms"] >= out["p50_latency_ms"] > 0
+    assert out["server"]["requests_total"] == 18 and out["server"]["errors_total"] == 0     # 6 warm + 12 counted
