@@ -40,6 +40,7 @@ def client(a) -> int:
     lock = threading.Lock()
     state = {"next": 0, "errors": 0}
     lat, done_at = [], []
+    kinds = {}                                   # failed requests by exception type
 
     def worker():
         while True:
@@ -57,8 +58,13 @@ def client(a) -> int:
                 data = r.read()
                 conn.close()
                 ok = r.status == 200 and "consensus" in json.loads(data)
-            except (OSError, ValueError):
+                if not ok:
+                    with lock:
+                        kinds[f"HTTP {r.status}"] = kinds.get(f"HTTP {r.status}", 0) + 1
+            except (OSError, ValueError) as e:
                 ok = False
+                with lock:
+                    kinds[type(e).__name__] = kinds.get(type(e).__name__, 0) + 1
             t1 = time.perf_counter()
             with lock:
                 if not ok:
@@ -74,7 +80,7 @@ def client(a) -> int:
     n = len(lat)
     # rate over the span in which counted answers arrived (the ramp of the warm questions is outside it)
     span = (max(done_at) - min(done_at)) if n > 1 else float("nan")
-    print(json.dumps({"answers": n, "errors": state["errors"], "wall_s": round(time.perf_counter() - t_start, 2),
+    print(json.dumps({"answers": n, "errors": state["errors"], "error_kinds": kinds, "wall_s": round(time.perf_counter() - t_start, 2),
                       "answers_per_s": round((n - 1) / span, 3) if n > 1 and span > 0 else None,
                       "p50_latency_ms": round(float(np.percentile(lat, 50)), 1) if n else None,
                       "p95_latency_ms": round(float(np.percentile(lat, 95)), 1) if n else None,

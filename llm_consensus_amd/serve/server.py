@@ -127,6 +127,12 @@ class ConsensusServer:
                 server._dispatch(self, "POST")
 
         class Server(ThreadingHTTPServer):
+            # socketserver listens with a backlog of 5: a few hundred clients that connect at the same
+            # moment (every connection of a closed loop after a step that finished them all) overflow
+            # it, and the kernel then drops or resets connections (1 s stalls, ECONNRESET) although
+            # the server is idle enough to take them (measured with benchmarks/http_load.py).
+            request_queue_size = 1024
+
             def handle_error(self, request, client_address):
                 # a client that resets its connection is not a server error worth a traceback
                 import sys
