@@ -38,6 +38,12 @@ unanimity) next to the OpenAI fields.
 With ``--api-key`` (or $CONSENSUS_API_KEY) the POST routes need ``Authorization: Bearer <key>``.
 SIGTERM drains the server: new requests get 503, the admitted ones are answered, then it exits.
 
+Malformed requests are answered, not crashed on: a bad ``Content-Length`` or a body that is not a
+JSON object gets 400, an announced body over ``max_body_bytes`` gets 413 before any of it is read,
+and socket reads and writes give up after ``io_timeout_s`` (half-sent requests, idle kept-alive
+connections, stream readers that stall), so no client can hold a handler thread for ever. The
+listen backlog is 1024.
+
 At most ``max_pending`` requests are accepted at a time (answered or not yet): one more gets
 429 with a Retry-After header instead of an unbounded wait behind engines that are already full.
 
@@ -93,7 +99,8 @@ class HTTPError(Exception):
 class ConsensusServer:
     def __init__(self, ensemble, host: str = "127.0.0.1", port: int = 8000, max_batch: int = 64,
                  batch_window_ms: float = 5.0, request_timeout_s: float = 600.0, continuous: bool = True,
-                 max_pending: int = 4096, api_key: Optional[str] = None) -> None:
+                 max_pending: int = 4096, api_key: Optional[str] = None, io_timeout_s: float = 60.0,
+                 max_body_bytes: int = 16 << 20) -> None:
         self.ensemble = ensemble
         self.continuous = continuous
         self.max_batch, self.window = max_batch, batch_window_ms / 1e3
@@ -103,6 +110,7 @@ class ConsensusServer:
         self.max_pending = max_pending
         self._outstanding = 0
         self.api_key = api_key or None           # when set, POST routes need "Authorization: Bearer <key>"
+        self.max_body_bytes = max_body_bytes     # a request that announces more gets 413 before a byte of it is read
         self.jobs: "queue.Queue[_Job]" = queue.Queue()
         self.cancels: "queue.Queue[_Job]" = queue.Queue()      # jobs whose client disconnected (see _cancel)
         self._cancels_served = False     # only the single-process continuous driver takes work out of engines
@@ -116,6 +124,11 @@ class ConsensusServer:
 
         class Handler(BaseHTTPRequestHandler):
             protocol_version = "HTTP/1.1"
+            # Socket reads and writes of a connection give up after this long: a client that opens a
+            # connection and sends nothing (or half a request, or stops reading its token stream)
+            # gives its handler thread back instead of holding it for ever. The wait for an ANSWER
+            # is not a socket operation and has its own limit (request_timeout_s).
+            timeout = io_timeout_s
 
             def log_message(self, fmt, *args):  # route access logs through our logger
                 log.debug("%s " + fmt, self.address_string(), *args)
@@ -489,11 +502,22 @@ class ConsensusServer:
                 if path == "/metrics":
                     return self._send(h, 200, self._metrics().encode(), "text/plain; version=0.0.4")
                 raise HTTPError(404, f"no route {path}")
-            n = int(h.headers.get("Content-Length") or 0)
+            try:
+                n = int(h.headers.get("Content-Length") or 0)
+            except ValueError:
+                n = -1
+            if n < 0:
+                h.close_connection = True        # the body's length is unknown: the connection cannot be reused
+                raise HTTPError(400, "bad Content-Length")
+            if n > self.max_body_bytes:
+                h.close_connection = True
+                raise HTTPError(413, f"request body of {n} bytes; at most {self.max_body_bytes} are accepted")
             try:
                 body = json.loads(h.rfile.read(n) or b"{}")
-            except json.JSONDecodeError as e:
+            except ValueError as e:              # not JSON, or not UTF-8
                 raise HTTPError(400, f"invalid JSON body: {e}")
+            if not isinstance(body, dict):
+                raise HTTPError(400, "the request body must be a JSON object")
             if path not in ("/v1/chat/completions", "/v1/completions", "/v1/embeddings", "/v1/score"):
                 raise HTTPError(404, f"no route {path}")
             if self.api_key is not None:
@@ -531,8 +555,8 @@ class ConsensusServer:
                                                         if e.status < 500 else "server_error", "code": e.status}})
             except (BrokenPipeError, ConnectionResetError):
                 pass                     # the client this error is for has gone (status 499 always ends here)
-        except (BrokenPipeError, ConnectionResetError):
-            pass
+        except (BrokenPipeError, ConnectionResetError, TimeoutError):
+            h.close_connection = True            # the client went away, or stopped sending / reading
         finally:
             with self._lock:
                 self.counters["latency_seconds_sum"] += time.perf_counter() - t0
@@ -833,6 +857,10 @@ def main(argv: Optional[list] = None) -> int:
                     help="seconds a request may take before it is answered 504 and its work is cancelled")
     ap.add_argument("--max-pending", type=int, default=4096,
                     help="requests accepted and not yet answered; one more gets 429 with Retry-After")
+    ap.add_argument("--io-timeout", type=float, default=60.0,
+                    help="seconds a socket read or write may take (a client that sends half a request, idles on a "
+                         "kept-alive connection or stops reading its stream gives its handler thread back)")
+    ap.add_argument("--max-body-mb", type=float, default=16.0, help="largest request body accepted (413 beyond)")
     ap.add_argument("--gpus", type=int, default=None,
                     help="run as this many ranks, one per GPU, started by this command (default: every replica "
                          "of the configured ensemble that the visible GPUs hold)")
@@ -878,7 +906,8 @@ def main(argv: Optional[list] = None) -> int:
     try:
         ConsensusServer(ens, args.host, args.port, args.max_batch, args.batch_window_ms,
                         request_timeout_s=args.request_timeout, continuous=not args.batched,
-                        max_pending=args.max_pending, api_key=args.api_key).serve_forever()
+                        max_pending=args.max_pending, api_key=args.api_key, io_timeout_s=args.io_timeout,
+                        max_body_bytes=int(args.max_body_mb * (1 << 20))).serve_forever()
     finally:
         if args.distributed:
             ens.close()

@@ -404,3 +404,49 @@ def test_score_route_and_decision_targets_agree_with_the_backend(server):
         with pytest.raises(urllib.error.HTTPError) as bad:
             _post(srv.port, path, body)
         assert bad.value.code == want, (path, body)
+
+
+def test_malformed_and_stalling_requests_cost_the_server_nothing():
+    """Bad Content-Length -> 400, an announced body over the limit -> 413 without reading it, a body
+    that is not a JSON object -> 400, and a client that sends half a request and goes quiet gets its
+    connection closed after the socket timeout; the server answers a normal request afterwards."""
+    import socket
+
+    cfg = config_from_dict({"strategy": "majority_vote", "sampling": {"temperature": 0.0, "max_new_tokens": 2},
+                            "models": {"default": {"preset": "tiny-llama", "seed": 1}},
+                            "members": [{"name": "a", "model": "default"}]})
+    ens = build_ensemble(cfg)
+    srv = ConsensusServer(ens, port=0, io_timeout_s=0.5, max_body_bytes=4096).start()
+    try:
+        def raw(request: bytes, wait=5.0) -> bytes:
+            with socket.create_connection(("127.0.0.1", srv.port), timeout=wait) as c:
+                c.sendall(request)
+                out = b""
+                try:
+                    while True:
+                        b = c.recv(65536)
+                        if not b:
+                            break
+                        out += b
+                except socket.timeout:
+                    pass
+                return out
+
+        head = b"POST /v1/completions HTTP/1.1\r\nHost: x\r\nContent-Type: application/json\r\n"
+        assert raw(head + b"Content-Length: banana\r\n\r\n").startswith(b"HTTP/1.1 400")
+        assert raw(head + b"Content-Length: -5\r\n\r\n").startswith(b"HTTP/1.1 400")
+        assert raw(head + b"Content-Length: 999999999\r\n\r\n").startswith(b"HTTP/1.1 413")      # nothing of the body sent
+        assert raw(head + b"Content-Length: 7\r\n\r\n[1,2,3]").startswith(b"HTTP/1.1 400")
+        assert raw(head + b"Content-Length: 4\r\n\r\n\xff\xfe\x00\x01").startswith(b"HTTP/1.1 400")
+        # half a request, then silence: the server closes the connection by itself
+        t0 = time.perf_counter()
+        got = raw(head + b"Content-Length: 100\r\n\r\n{\"model\":", wait=10.0)
+        assert time.perf_counter() - t0 < 5.0 and not got.startswith(b"HTTP/1.1 200")
+        # a connection that never sends a byte
+        t0 = time.perf_counter()
+        assert raw(b"", wait=10.0) == b"" and time.perf_counter() - t0 < 5.0
+        code, out = _post(srv.port, "/v1/completions", {"model": "default", "prompt": "still there?", "max_tokens": 2})
+        assert code == 200 and len(out["choices"]) == 1
+        assert threading.active_count() < 20          # no handler threads left behind
+    finally:
+        srv.shutdown()
