@@ -39,7 +39,7 @@ def client(a) -> int:
     qs = make_questions(np.random.default_rng(a.seed), a.questions + a.warm, a.prompt_len)
     lock = threading.Lock()
     state = {"next": 0, "errors": 0}
-    lat, done_at = [], []
+    lat, done_at, ttft = [], [], []
     kinds = {}                                   # failed requests by exception type
 
     def worker():
@@ -49,15 +49,36 @@ def client(a) -> int:
                 if i >= len(qs):
                     return
                 state["next"] = i + 1
-            body = json.dumps({"messages": [{"role": "user", "content": qs[i]}]}).encode()
+            if a.stream:      # one member model's tokens as server-sent events
+                body = json.dumps({"model": a.stream, "prompt": qs[i], "max_tokens": a.new_tokens, "stream": True}).encode()
+            else:
+                body = json.dumps({"messages": [{"role": "user", "content": qs[i]}]}).encode()
             t0 = time.perf_counter()
+            t_first = None
             try:
                 conn = http.client.HTTPConnection("127.0.0.1", a.port, timeout=a.timeout)
-                conn.request("POST", "/v1/chat/completions", body, {"Content-Type": "application/json"})
+                conn.request("POST", "/v1/completions" if a.stream else "/v1/chat/completions", body,
+                             {"Content-Type": "application/json"})
                 r = conn.getresponse()
-                data = r.read()
-                conn.close()
-                ok = r.status == 200 and "consensus" in json.loads(data)
+                if a.stream and r.status == 200:
+                    pieces, finished, done = 0, False, False
+                    for raw in r:
+                        line = raw.strip()
+                        if line == b"data: [DONE]":
+                            done = True
+                            break
+                        if line.startswith(b"data: {"):
+                            c = json.loads(line[6:])["choices"][0]
+                            if c.get("text"):
+                                pieces += 1
+                                t_first = t_first or time.perf_counter()
+                            finished = finished or bool(c.get("finish_reason"))
+                    conn.close()
+                    ok = done and finished and pieces > 0
+                else:
+                    data = r.read()
+                    conn.close()
+                    ok = r.status == 200 and "consensus" in json.loads(data)
                 if not ok:
                     with lock:
                         kinds[f"HTTP {r.status}"] = kinds.get(f"HTTP {r.status}", 0) + 1
@@ -72,6 +93,8 @@ def client(a) -> int:
                 elif i >= a.warm:                # the first questions fill the pipeline and are not counted
                     lat.append((t1 - t0) * 1e3)
                     done_at.append(t1)
+                    if t_first is not None:
+                        ttft.append((t_first - t0) * 1e3)
 
     ts = [threading.Thread(target=worker, daemon=True) for _ in range(a.in_flight)]
     t_start = time.perf_counter()
@@ -84,7 +107,9 @@ def client(a) -> int:
                       "answers_per_s": round((n - 1) / span, 3) if n > 1 and span > 0 else None,
                       "p50_latency_ms": round(float(np.percentile(lat, 50)), 1) if n else None,
                       "p95_latency_ms": round(float(np.percentile(lat, 95)), 1) if n else None,
-                      "p99_latency_ms": round(float(np.percentile(lat, 99)), 1) if n else None}), flush=True)
+                      "p99_latency_ms": round(float(np.percentile(lat, 99)), 1) if n else None,
+                      **({"p50_first_token_ms": round(float(np.percentile(ttft, 50)), 1),
+                          "p99_first_token_ms": round(float(np.percentile(ttft, 99)), 1)} if ttft else {})}), flush=True)
     return 0 if n and not state["errors"] else 1
 
 
@@ -99,6 +124,9 @@ def main(argv=None) -> int:
     ap.add_argument("--new-tokens", type=int, default=64)
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--timeout", type=float, default=300.0)
+    ap.add_argument("--stream", nargs="?", const="first", default=None, metavar="MODEL",
+                    help="stream completions of ONE member model (default: the first) as server-sent events instead "
+                         "of asking consensus questions; adds time to first token")
     ap.add_argument("--client", action="store_true", help="(internal) run the client half against --port")
     ap.add_argument("--port", type=int, default=0)
     a = ap.parse_args(argv)
@@ -125,10 +153,13 @@ def main(argv=None) -> int:
     init_s = time.perf_counter() - t0
     srv = ConsensusServer(ens, port=0, max_batch=max(64, a.in_flight), max_pending=4 * a.in_flight,
                           request_timeout_s=a.timeout).start()
+    extra = []
+    if a.stream:
+        extra = ["--stream", sorted(ens.backends)[0] if a.stream == "first" else a.stream, "--new-tokens", str(a.new_tokens)]
     try:
         p = subprocess.run([sys.executable, str(Path(__file__).resolve()), "--client", "--port", str(srv.port),
                             "--in-flight", str(a.in_flight), "--questions", str(a.questions), "--warm", str(a.warm),
-                            "--prompt-len", str(a.prompt_len), "--seed", str(a.seed), "--timeout", str(a.timeout)],
+                            "--prompt-len", str(a.prompt_len), "--seed", str(a.seed), "--timeout", str(a.timeout)] + extra,
                            capture_output=True, text=True, timeout=a.timeout * 4)
     finally:
         srv.shutdown()
@@ -137,7 +168,9 @@ def main(argv=None) -> int:
         out = json.loads(line)
     except ValueError:
         out = {"error": (p.stderr or p.stdout)[-400:]}
-    out.update({"mode": "closed loop over HTTP: every connection posts its next question when its answer is in",
+    out.update({"mode": ("closed loop over HTTP: every connection streams its next completion when the last one ended"
+                         if a.stream else
+                         "closed loop over HTTP: every connection posts its next question when its answer is in"),
                 "connections": a.in_flight, "models": a.models, "prompt_len": a.prompt_len, "new_tokens": a.new_tokens,
                 "device": a.device, "init_s": round(init_s, 1),
                 "server": {k: v for k, v in srv.counters.items()}})

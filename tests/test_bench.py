@@ -264,3 +264,10 @@ def test_http_load_benchmark_runs_a_closed_loop_through_the_server():
     assert out["answers"] == 12 and out["errors"] == 0 and out["answers_per_s"] > 0
     assert out["p99_latency_ms"] >= out["p95_latency_ms"] >= out["p50_latency_ms"] > 0
     assert out["server"]["requests_total"] == 18 and out["server"]["errors_total"] == 0     # 6 warm + 12 counted
+    # the same loop with every connection streaming one member model's tokens
+    p = subprocess.run([sys.executable, str(root / "benchmarks" / "http_load.py"), "--device", "cpu", "--models",
+                        "tiny-llama", "--in-flight", "4", "--questions", "8", "--prompt-len", "96", "--new-tokens", "6",
+                        "--stream"], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-2000:]
+    out = json.loads(p.stdout.strip().splitlines()[-1])
+    assert out["answers"] == 8 and out["errors"] == 0 and 0 < out["p50_first_token_ms"] <= out["p50_latency_ms"]
