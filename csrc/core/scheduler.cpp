@@ -132,7 +132,8 @@ void Scheduler::preempt(int gid) {
 void Scheduler::ensure_decode_capacity() {
   // Oldest groups first; a group that cannot get its blocks takes them from the youngest
   // admitted request: a prompt that is still being prefilled (it has produced nothing yet),
-  // then the youngest running group.
+  // then the youngest running group. When the group that comes up short IS the youngest
+  // running group, it is the one that starts over: the older groups keep what they hold.
   for (size_t gi = 0; gi < running_.size(); ++gi) {
     const int gid = running_[gi];
     bool restart = true;
@@ -145,6 +146,9 @@ void Scheduler::ensure_decode_capacity() {
           preempt(prefilling_.back());
         } else if (running_.size() > gi + 1) {
           preempt(running_.back());
+        } else if (gi > 0) {
+          preempt(gid);          // running_ ends before gi now: the pass is over
+          break;
         } else {
           // this is the only group left: the request alone exceeds the pool
           throw std::runtime_error("Scheduler: KV pool too small for a single running request");

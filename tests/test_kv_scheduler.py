@@ -397,3 +397,151 @@ def test_schedule_ahead_refuses_when_prompts_wait():
     assert sched.schedule_ahead(plan).kind == core.StepPlan.Kind.Idle
     finish_step(sched, plan)
     assert sched.schedule().kind == core.StepPlan.Kind.Prefill
+
+
+# ---------------------------------------------------------------- the whole scheduler under random traffic
+
+@settings(max_examples=200, deadline=None, derandomize=True)
+@given(st.data())
+def test_scheduler_under_random_traffic_keeps_its_invariants(data):
+    """Random pool sizes and switches (optimistic admission, mixed steps, prefix cache), random
+    arrivals (generate with 1-4 chains and stop tokens, score, embed), random aborts, decode steps
+    planned ahead of their results at random. Whatever the interleaving: no step throws, no two
+    tokens of a step are given the same KV slot, every slot lies in a block of its sequence's
+    table, limits are kept, every request that was not aborted finishes exactly once with the
+    tokens the (deterministic) fake model produces, and all blocks come back."""
+    VOCAB = 1000
+    blocks = data.draw(st.integers(24, 96), label="blocks")
+    bs = data.draw(st.sampled_from([4, 8]), label="block_size")
+    kv = core.KVManager(blocks, bs, data.draw(st.booleans(), label="prefix_cache"))
+    cfg = core.SchedulerConfig()
+    cfg.max_batch_seqs = data.draw(st.integers(4, 16), label="max_batch")
+    cfg.max_prefill_tokens = data.draw(st.sampled_from([16, 32, 64]), label="max_prefill")
+    cfg.optimistic_admission = data.draw(st.booleans(), label="optimistic")
+    cfg.mix_decode = data.draw(st.booleans(), label="mix_decode")
+    sched = core.Scheduler(kv, cfg)
+    events = data.draw(st.lists(st.tuples(st.integers(0, 9), st.integers(0, 10_000)), max_size=60), label="events")
+
+    want = {}            # request id -> (kind, last prompt token, n, max_new, eos)
+    aborted, finished = set(), {}
+    pending = None       # a decode step planned ahead, with the output of the step before it
+    last_out = None
+    ev = list(events)
+    for step in range(len(events) + 3000):
+        if ev:
+            op, x = ev.pop(0)
+            if op <= 4:
+                p = core.SamplingParams()
+                p.max_new_tokens = 1 + (x // 30) % 10
+                eos = None
+                if x % 3 == 0:
+                    p.eos_id = eos = (x // 7) % VOCAB
+                else:
+                    p.ignore_eos = True
+                n = [1, 1, 2, 4][x % 4]
+                prompt = toks(1 + x % 30, (x * 13) % 500)
+                try:
+                    rid = sched.add_request(core.RequestKind.Generate, prompt, n, p)
+                    want[rid] = ("gen", int(prompt[-1]), n, p.max_new_tokens, eos)
+                except ValueError:
+                    pass                                   # can never fit this pool: refused at the door
+            elif op in (5, 6):
+                kind = core.RequestKind.Score if op == 5 else core.RequestKind.Embed
+                try:
+                    want[sched.add_request(kind, toks(1 + x % 40, (x * 7) % 500))] = ("prefill_only",)
+                except ValueError:
+                    pass
+            elif op == 7 and pending is None:
+                live = sorted(set(want) - set(finished) - aborted)
+                if live:
+                    rid = live[x % len(live)]
+                    sched.abort_request(rid)
+                    aborted.add(rid)
+        if pending is not None:
+            plan, pending = pending, None
+        else:
+            plan = sched.schedule()
+        if plan.kind == core.StepPlan.Kind.Idle:
+            if not ev:
+                break
+            continue
+        slots = np.asarray(plan.slot_mapping)
+        live_slots = slots[slots >= 0]
+        assert len(set(live_slots.tolist())) == len(live_slots), "two tokens of one step share a KV slot"
+        assert (live_slots < blocks * bs).all()
+        if plan.kind == core.StepPlan.Kind.Prefill:
+            assert plan.cu_q[-1] == len(plan.token_ids) == len(plan.positions) == len(slots)
+            assert len(plan.token_ids) <= cfg.max_prefill_tokens + cfg.max_batch_seqs       # prompt budget + riders
+            finish_step(sched, plan, vocab=VOCAB)
+            last_out = None
+        else:
+            B = len(plan.seq_ids)
+            assert 0 < B <= cfg.max_batch_seqs
+            bt = np.asarray(plan.block_tables)
+            pos = np.asarray(plan.positions)
+            assert (bt[np.arange(B), pos // bs] == slots // bs).all(), "a token's slot is outside its sequence's blocks"
+            toks_in = np.asarray(plan.token_ids)
+            if plan.ahead:
+                toks_in = last_out[np.asarray(plan.src_rows)]
+            out = ((toks_in + 1) % VOCAB).astype(np.int32)
+            if step % 2 == 0:
+                nxt = sched.schedule_ahead(plan)
+                if nxt.kind == core.StepPlan.Kind.Decode:
+                    pending = nxt
+            sched.complete_decode(plan, out, np.zeros(B, dtype=np.float32))
+            last_out = out
+        for f in sched.take_finished():
+            assert f.request_id not in finished, "a request finished twice"
+            finished[f.request_id] = f
+    else:
+        raise AssertionError("the scheduler did not drain")
+    assert not sched.has_work()
+    assert set(want) - aborted <= set(finished)
+    for rid, f in finished.items():
+        if rid in aborted:
+            continue
+        spec = want[rid]
+        if spec[0] == "prefill_only":
+            assert f.chains[0].reason == core.FinishReason.PrefillOnly
+            continue
+        _, last, n, max_new, eos = spec
+        assert len(f.chains) == n
+        for c, ch in enumerate(f.chains):
+            t = list(ch.tokens)
+            assert 1 <= len(t) <= max_new and t[0] == (last + 1 + c) % VOCAB
+            assert all((t[i + 1] - t[i]) % VOCAB == 1 for i in range(len(t) - 1))
+            if eos is not None and eos in t:
+                assert t.index(eos) == len(t) - 1 and ch.reason == core.FinishReason.Eos
+            else:
+                assert len(t) == max_new and ch.reason == core.FinishReason.Length
+    assert kv.available_blocks() == blocks
+
+
+def test_youngest_running_group_that_comes_up_short_starts_over_itself():
+    """Found by the random-traffic test: 24 blocks of 4, optimistic admission, three requests whose
+    chains cross block boundaries in the same decode step. The two older groups take the free
+    blocks; the youngest finds none and has no younger victim. It has to give way itself (and be
+    recomputed later), not fail the step with "pool too small for a single running request"."""
+    kv = core.KVManager(24, 4, False)
+    cfg = core.SchedulerConfig()
+    cfg.max_batch_seqs, cfg.max_prefill_tokens, cfg.optimistic_admission, cfg.mix_decode = 10, 16, True, False
+    sched = core.Scheduler(kv, cfg)
+    fin, ids = [], []
+    arrivals = [(18, 4, 4), (3, 2, 7), (10, 4, 6)]            # prompt tokens, chains, new tokens; one per step
+    for step in range(200):
+        if arrivals:
+            plen, n, new = arrivals.pop(0)
+            p = core.SamplingParams(); p.max_new_tokens, p.ignore_eos = new, True
+            ids.append(sched.add_request(core.RequestKind.Generate, toks(plen, 100 * len(ids)), n, p))
+        plan = sched.schedule()
+        if plan.kind == core.StepPlan.Kind.Idle:
+            break
+        finish_step(sched, plan, vocab=1000)
+        fin += sched.take_finished()
+    assert sorted(f.request_id for f in fin) == ids and sched.num_preemptions >= 1
+    for f in fin:
+        for ch in f.chains:
+            t = list(ch.tokens)
+            assert all((t[i + 1] - t[i]) % 1000 == 1 for i in range(len(t) - 1))
+    assert [len(f.chains[0].tokens) for f in sorted(fin, key=lambda f: f.request_id)] == [4, 7, 6]
+    assert kv.available_blocks() == 24
