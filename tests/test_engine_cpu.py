@@ -236,3 +236,102 @@ def test_backend_handle_cancel_completes_the_handle_with_an_error():
     assert not a.cancel() and not b.cancel()         # finished handles stay as they are
     st = be.engine.stats()                           # nothing is held but what the prefix cache keeps for reuse
     assert st["kv.blocks_free"] + st["kv.blocks_cached"] == st["kv.blocks_total"] and st["requests.cancelled"] == 1
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_engine_under_random_traffic_matches_solo_runs(seed):
+    """Random engine settings (mixed steps, optimistic admission with preemption, decode steps
+    launched ahead, prefix cache, small KV pools), random arrivals between steps (1-4 chains,
+    greedy and sampled, with decision targets, score and embed requests), random cancellations.
+    Every request that was not cancelled must come out as it does alone in a fresh engine (a
+    chain's tokens depend on its seed, not on its batch, its restarts or its neighbours), a
+    cancelled one as Aborted, and every KV block must be back. Where a chain parts from its solo
+    run it must be rounding, and the test checks that it is: bf16 rows computed in batches of
+    another shape differ in the last bit, so a greedy chain may take the other side of a tie (the
+    two tokens' log-probabilities, scored at that position, are within 0.01: a random-init model
+    is full of near-ties) and a sampled chain may land on a NEIGHBOURING token of the inverse-CDF
+    walk (the draw goes through the vocabulary in index order, a boundary that moved by 1e-3 of
+    the mass is a step of an index or two). Anything else is a bug."""
+    rng = np.random.default_rng(1000 + seed)
+    cfg = get_preset("tiny-llama")
+    model = TransformerModel.random_init(cfg, "cpu", seed=9, std=0.1)
+    kw = dict(block_size=16, use_graphs=False, max_model_len=256)
+    knobs = dict(num_kv_blocks=int(rng.integers(28, 96)), max_batch_seqs=int(rng.integers(4, 12)),
+                 max_prefill_tokens=int(rng.choice([32, 48, 96])), mix_decode=bool(rng.integers(2)),
+                 optimistic_admission=bool(rng.integers(2)), pipeline_decode=bool(rng.integers(2)),
+                 enable_prefix_cache=bool(rng.integers(2)))
+    eng = Engine(model, **kw, **knobs)
+    shared_head = rng.integers(5, 250, size=40).tolist()       # some prompts share a head: prefix-cache hits
+
+    def new_request():
+        kind = rng.choice(["gen", "gen", "gen", "score", "embed"])
+        n_prompt = int(rng.integers(3, 90))
+        prompt = rng.integers(5, 250, size=n_prompt).tolist()
+        if rng.integers(3) == 0:
+            prompt = shared_head + prompt[:40]
+        if kind == "gen":
+            p = greedy_params(int(rng.integers(1, 14)), seed=int(rng.integers(1 << 20)),
+                              temperature=float(rng.choice([0.0, 0.8])))
+            n = int(rng.choice([1, 1, 2, 4]))
+            dec = [7, 9, 11] if rng.integers(2) else None
+            return dict(prompt_ids=prompt, n=n, params=p, decision_ids=dec)
+        if kind == "score":
+            return dict(prompt_ids=prompt, kind=core.RequestKind.Score, score_ids=[3, 4])
+        return dict(prompt_ids=prompt, kind=core.RequestKind.Embed)
+
+    live, specs, cancelled = [], {}, set()
+    for step in range(400):
+        if step < 60:
+            for _ in range(int(rng.integers(0, 3))):
+                spec = new_request()
+                try:
+                    rid = eng.submit(**spec)
+                except ValueError:
+                    continue                            # larger than the whole pool: refused at the door
+                specs[rid] = spec
+                live.append(rid)
+            if live and rng.integers(5) == 0:
+                rid = live[int(rng.integers(len(live)))]
+                if eng.cancel(rid):
+                    cancelled.add(rid)
+        if not eng.step() and step >= 60:
+            break
+        live = [r for r in live if r in eng._reqs]
+    assert not eng.has_work() and not eng._reqs
+    st = eng.stats()
+    assert st["kv.blocks_free"] + st["kv.blocks_cached"] == st["kv.blocks_total"], (knobs, st)
+    assert st.get("requests.cancelled", 0) <= len(cancelled)
+
+    solo = Engine(model, **kw, num_kv_blocks=96, enable_prefix_cache=False, pipeline_decode=False)
+    drifted = []
+    for rid, spec in specs.items():
+        out = eng.pop_result(rid)
+        assert out is not None, (rid, knobs)
+        if rid in cancelled and set(out.finish_reasons) == {"Aborted"}:
+            continue                                    # (a cancel that came after the last token changes nothing)
+        r = solo.submit(**spec)
+        solo.run_until_done()
+        want = solo.pop_result(r)
+        if out.token_ids != want.token_ids:
+            assert [len(c) for c in out.token_ids] == [len(c) for c in want.token_ids]
+            for g, w in zip(out.token_ids, want.token_ids):
+                if g == w:
+                    continue
+                i = next(k for k, (a, b) in enumerate(zip(g, w)) if a != b)
+                if spec["params"].temperature > 0:
+                    assert abs(g[i] - w[i]) <= 4, (rid, knobs, i, g, w)
+                else:
+                    r2 = solo.submit(list(spec["prompt_ids"]) + list(w[:i]), kind=core.RequestKind.Score,
+                                     score_ids=[int(g[i]), int(w[i])])
+                    solo.run_until_done()
+                    lp = solo.pop_result(r2).scores
+                    assert abs(lp[0] - lp[1]) < 0.01, (rid, knobs, i, g, w, lp)
+            drifted.append(rid)
+            continue
+        if spec.get("kind") == core.RequestKind.Embed:
+            assert np.allclose(out.embedding, want.embedding, atol=2e-2)
+        if spec.get("score_ids") is not None:
+            assert np.allclose(out.scores, want.scores, atol=5e-2)        # bf16 rows in batches of other shapes
+        if spec.get("decision_ids") is not None:
+            assert np.allclose(out.decision_logprobs, want.decision_logprobs, atol=5e-2)
+    assert len(drifted) <= max(3, len(specs) // 10), (drifted, knobs)
