@@ -114,6 +114,20 @@ PlacementPlan plan_placement(const std::vector<MemberSpec>& members, int num_gpu
   }
   if (g_min < 0) {
     plan.error = "ensemble does not fit in " + std::to_string(num_gpus) + " GPUs";
+    // Name what can never fit, whatever its neighbours: a model whose group is larger than the
+    // node, or whose per-GPU share alone exceeds what a GPU offers.
+    for (const auto& u : units) {
+      const std::string& who = members[u.member_idx[0]].name;
+      if (u.group > num_gpus) {
+        plan.error += ": '" + who + "' wants a group of " + std::to_string(u.group) + " GPUs";
+        break;
+      }
+      if (u.bytes_per_gpu > cap) {
+        plan.error += ": '" + who + "' needs " + std::to_string(u.bytes_per_gpu >> 20) + " MiB per GPU (weights + KV), " +
+                      std::to_string(cap >> 20) + " MiB are available; shard it further (tp / ep)";
+        break;
+      }
+    }
     return plan;
   }
 
