@@ -231,7 +231,10 @@ class EngineBackend(Backend):
             if not chains or not all(chains):
                 continue
             texts = self._texts(chains)
-            cuts = [self._first_stop(t, stops) for t in texts]
+            # A trailing replacement character may be the first bytes of a multi-byte character that
+            # the next tokens complete: it is not text yet and must not match a stop sequence (the
+            # finished chain is searched whole in _harvest).
+            cuts = [self._first_stop(t[:-1] if t.endswith("\ufffd") else t, stops) for t in texts]
             if any(c < 0 for c in cuts):
                 continue
             if rid in self._streams:
