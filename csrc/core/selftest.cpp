@@ -12,7 +12,9 @@
 //   3. threads: each thread owns its sessions/scheduler (the design's ownership rule) while
 //      all of them hammer one shared Metrics object.
 // Exit status 0 = all invariants held (sanitizer findings abort on their own).
+#include <algorithm>
 #include <cstdio>
+#include <stdexcept>
 #include <memory>
 #include <thread>
 #include <vector>
@@ -147,6 +149,112 @@ static void run_scheduler(uint64_t seed, int n_requests, Metrics* metrics) {
   CHECK(st.blocks_free + st.blocks_cached == num_blocks);   // nothing leaked, nothing double-freed
 }
 
+// The scheduler with every switch at random: small pools (optimistic admission has to preempt and
+// recompute), mixed steps (decoding chains ride along in prefill steps), decode steps planned ahead
+// of their results, aborts at step boundaries. Besides the block accounting at the end, no two
+// tokens of a step may be given the same KV slot.
+static void run_scheduler_hard(uint64_t seed, int n_requests, Metrics* metrics) {
+  SplitMix64 rng(seed);
+  const int bs = rng.below(2) ? 4 : 8;
+  const int num_blocks = 32 + static_cast<int>(rng.below(64));
+  auto kv = std::make_shared<KVManager>(num_blocks, bs, /*enable_prefix_cache=*/rng.below(2) != 0);
+  SchedulerConfig sc;
+  sc.max_batch_seqs = 4 + static_cast<int>(rng.below(12));
+  sc.max_prefill_tokens = 16 << rng.below(3);
+  sc.optimistic_admission = rng.below(2) != 0;
+  sc.mix_decode = rng.below(2) != 0;
+  Scheduler sched(kv, sc);
+  int submitted = 0, settled = 0;      // settled = finished or aborted
+  std::vector<int> live;
+  std::vector<int32_t> toks, last_out;
+  std::vector<float> lps;
+  bool have_pending = false;
+  StepPlan pending;
+  int steps = 0;
+  while (settled < n_requests || sched.has_work()) {
+    CHECK(++steps < 400000);
+    while (submitted < n_requests && sched.num_waiting() < 4 && rng.below(3) == 0) {
+      const int len = 1 + static_cast<int>(rng.below(28));
+      std::vector<int32_t> prompt(len);
+      const bool shared = rng.below(3) == 0;
+      for (int i = 0; i < len; ++i) prompt[i] = shared ? i : static_cast<int32_t>(rng.below(500));
+      SamplingParams p;
+      p.max_new_tokens = 1 + static_cast<int>(rng.below(10));
+      p.eos_id = 7;
+      p.ignore_eos = rng.below(2);
+      const uint64_t k = rng.below(10);
+      const RequestKind kind = k < 7 ? RequestKind::Generate : (k < 9 ? RequestKind::Score : RequestKind::Embed);
+      const int n = kind == RequestKind::Generate ? 1 + static_cast<int>(rng.below(4)) : 1;
+      ++submitted;
+      try {
+        live.push_back(sched.add_request(kind, std::move(prompt), n, p));
+      } catch (const std::exception&) {
+        ++settled;                      // can never fit this pool: refused at the door
+      }
+    }
+    if (!have_pending && !live.empty() && rng.below(12) == 0) {
+      const size_t i = rng.below(live.size());
+      sched.abort_request(live[i]);     // its FinishedRequest (reason Aborted) is counted below
+    }
+    StepPlan plan;
+    if (have_pending) {
+      plan = std::move(pending);
+      have_pending = false;
+    } else {
+      plan = sched.schedule();
+    }
+    if (plan.kind == StepPlan::Idle) {
+      for (auto& f : sched.take_finished()) {
+        ++settled;
+        live.erase(std::remove(live.begin(), live.end(), f.request_id), live.end());
+      }
+      continue;
+    }
+    std::vector<int32_t> slots(plan.slot_mapping.begin(), plan.slot_mapping.end());
+    slots.erase(std::remove_if(slots.begin(), slots.end(), [](int32_t v) { return v < 0; }), slots.end());
+    std::sort(slots.begin(), slots.end());
+    CHECK(std::adjacent_find(slots.begin(), slots.end()) == slots.end());
+    CHECK(slots.empty() || slots.back() < num_blocks * bs);
+    if (plan.kind == StepPlan::Prefill) {
+      auto layout = sched.prefill_sample_layout(plan);
+      int n = static_cast<int>(layout.size());
+      if (plan.rider_first >= 0) n += static_cast<int>(plan.cu_q.size()) - 1 - plan.rider_first;
+      toks.assign(n, 0);
+      lps.assign(n, -1.f);
+      for (auto& t : toks) t = static_cast<int32_t>(rng.below(40));
+      sched.complete_prefill(plan, toks.data(), lps.data(), n);
+      last_out.clear();
+    } else {
+      const int B = static_cast<int>(plan.seq_ids.size());
+      CHECK(B > 0 && B <= sc.max_batch_seqs);
+      if (plan.ahead) {
+        CHECK(static_cast<int>(plan.src_rows.size()) == B);
+        for (int r : plan.src_rows) CHECK(r >= 0 && r < static_cast<int>(last_out.size()));
+      }
+      toks.assign(B, 0);
+      lps.assign(B, -1.f);
+      for (auto& t : toks) t = static_cast<int32_t>(rng.below(40));
+      if (rng.below(2)) {
+        StepPlan nxt = sched.schedule_ahead(plan);
+        if (nxt.kind == StepPlan::Decode) {
+          pending = std::move(nxt);
+          have_pending = true;
+        }
+      }
+      sched.complete_decode(plan, toks.data(), lps.data());
+      last_out = toks;
+      metrics->inc("decode.tokens", B);
+    }
+    for (auto& f : sched.take_finished()) {
+      ++settled;
+      live.erase(std::remove(live.begin(), live.end(), f.request_id), live.end());
+    }
+  }
+  CHECK(live.empty());
+  const KVStats st = kv->stats();
+  CHECK(st.blocks_free + st.blocks_cached == num_blocks);
+}
+
 int main(int argc, char** argv) {
   const int threads = argc > 1 ? std::atoi(argv[1]) : 4;
   const int scale = argc > 2 ? std::atoi(argv[2]) : 1;
@@ -157,6 +265,7 @@ int main(int argc, char** argv) {
     pool.emplace_back([&, t] {
       forced[t] = run_sessions(1000 + t, 300 * scale, &metrics);
       run_scheduler(2000 + t, 150 * scale, &metrics);
+      for (int k = 0; k < 40 * scale; ++k) run_scheduler_hard(3000 + 100 * t + k, 60, &metrics);
     });
   for (auto& th : pool) th.join();
   CHECK(metrics.counter("sessions") == 300.0 * scale * threads);
