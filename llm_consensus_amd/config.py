@@ -137,6 +137,56 @@ class ConsensusConfig:
         for m in self.members:
             if m.model not in self.models:
                 raise ValueError(f"member {m.name!r} refers to unknown model {m.model!r}")
+            if m.role not in ("member", "judge", "embedder"):
+                raise ValueError(f"member {m.name!r}: unknown role {m.role!r} (member | judge | embedder)")
+            if not _is_number(m.weight) or m.weight < 0:
+                raise ValueError(f"member {m.name!r}: weight must be a number >= 0, not {m.weight!r}")
+        if self.tie_break not in ("lowest_class", "first_voter", "highest_weight"):
+            raise ValueError(f"unknown tie_break {self.tie_break!r} (lowest_class | first_voter | highest_weight)")
+        if self.placement not in ("pack", "spread"):
+            raise ValueError(f"unknown placement {self.placement!r} (pack | spread)")
+        if not isinstance(self.choices, str) or len(self.choices) < 2 or len(set(self.choices)) != len(self.choices):
+            raise ValueError(f"choices must be a string of at least two distinct letters, not {self.choices!r}")
+        for name, lo in (("k_chains", 1), ("samples_per_member", 1), ("micro_batches", 1), ("min_micro_batch", 1),
+                         ("fixed_proposer", 0)):
+            v = getattr(self, name)
+            if not _is_int(v) or v < lo:
+                raise ValueError(f"{name} must be an integer >= {lo}, not {v!r}")
+        if self.deadline_s is not None and (not _is_number(self.deadline_s) or self.deadline_s <= 0):
+            raise ValueError(f"deadline_s must be a positive number of seconds, not {self.deadline_s!r}")
+        s = self.sampling
+        if not _is_number(s.temperature) or s.temperature < 0:
+            raise ValueError(f"sampling.temperature must be a number >= 0 (0 = greedy), not {s.temperature!r}")
+        if not _is_number(s.top_p) or not 0 < s.top_p <= 1:
+            raise ValueError(f"sampling.top_p must lie in (0, 1], not {s.top_p!r}")
+        if not _is_int(s.top_k) or s.top_k < 0:
+            raise ValueError(f"sampling.top_k must be an integer >= 0 (0 = off), not {s.top_k!r}")
+        if not _is_int(s.max_new_tokens) or s.max_new_tokens < 1:
+            raise ValueError(f"sampling.max_new_tokens must be an integer >= 1, not {s.max_new_tokens!r}")
+        if not _is_int(s.seed):
+            raise ValueError(f"sampling.seed must be an integer, not {s.seed!r}")
+        for spec in self.models.values():
+            who = f"model {spec.name!r}"
+            for name, lo in (("tp", 1), ("ep", 1), ("kv_blocks", 0), ("max_batch_seqs", 1), ("max_prefill_tokens", 1),
+                             ("max_model_len", 0)):
+                v = getattr(spec, name)
+                if not _is_int(v) or v < lo:
+                    raise ValueError(f"{who}: {name} must be an integer >= {lo}, not {v!r}")
+            bs = spec.kv_block_size
+            if not _is_int(bs) or bs < 8 or bs & (bs - 1):
+                raise ValueError(f"{who}: kv_block_size must be a power of two >= 8 (the attention kernels read keys "
+                                 f"in runs of 8), not {bs!r}")
+            if not _is_number(spec.kv_fraction) or not 0 < spec.kv_fraction < 1:
+                raise ValueError(f"{who}: kv_fraction must lie in (0, 1), not {spec.kv_fraction!r}")
+            if spec.ep_mode not in ("allreduce", "a2a"):
+                raise ValueError(f"{who}: unknown ep_mode {spec.ep_mode!r} (allreduce | a2a)")
+            if spec.chat_format not in ("none", "llama3", "chatml", "mistral"):
+                raise ValueError(f"{who}: unknown chat_format {spec.chat_format!r} (none | llama3 | chatml | mistral)")
+            gb = spec.graph_batch_buckets
+            if not isinstance(gb, (list, tuple)) or not gb or not all(_is_int(b) and b >= 1 for b in gb):
+                raise ValueError(f"{who}: graph_batch_buckets must be a list of positive integers, not {gb!r}")
+            if not spec.path and not spec.preset:
+                raise ValueError(f"{who}: give a checkpoint `path` or a `preset`")
 
     def session_config(self) -> "core.SessionConfig":
         sc = core.SessionConfig()
@@ -178,6 +228,14 @@ class ConsensusConfig:
 
     def to_dict(self) -> Dict[str, Any]:
         return dataclasses.asdict(self)
+
+
+def _is_int(v) -> bool:
+    return isinstance(v, int) and not isinstance(v, bool)
+
+
+def _is_number(v) -> bool:
+    return isinstance(v, (int, float)) and not isinstance(v, bool)
 
 
 def _build(cls, data: Dict[str, Any]):

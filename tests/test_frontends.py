@@ -379,3 +379,28 @@ def test_sigterm_drains_the_server_admitted_requests_are_answered_new_ones_refus
     finally:
         if proc.poll() is None:
             proc.kill()
+
+
+def test_bad_config_values_are_refused_with_a_message_that_names_them():
+    """A value that would fail deep inside an engine (or silently fall back to a default) is an
+    error at load time; every shipped config passes the same checks."""
+    import glob
+
+    from llm_consensus_amd.config import config_from_dict, load_config
+
+    for f in sorted(glob.glob(str(Path(__file__).resolve().parents[1] / "configs" / "*"))):
+        load_config(f)
+    for bad, word in (
+        ({"sampling": {"temperature": "hot"}}, "temperature"), ({"sampling": {"max_new_tokens": -3}}, "max_new_tokens"),
+        ({"sampling": {"top_p": 0}}, "top_p"), ({"models": {"default": {"preset": "tiny-llama", "tp": 0}}}, "tp"),
+        ({"models": {"default": {"preset": "tiny-llama", "kv_block_size": 7}}}, "kv_block_size"),
+        ({"members": [{"name": "a", "model": "default", "role": "wizard"}]}, "role"),
+        ({"strategy": "self_consistency", "k_chains": 0}, "k_chains"), ({"tie_break": "coin"}, "tie_break"),
+        ({"placement": "everywhere"}, "placement"), ({"members": [{"name": "a", "model": "default", "weight": -1}]}, "weight"),
+        ({"choices": "A"}, "choices"), ({"deadline_s": -1}, "deadline_s"),
+        ({"models": {"default": {"preset": "tiny-llama", "chat_format": "weird"}}}, "chat_format"),
+        ({"models": {"default": {"preset": "tiny-llama", "ep_mode": "x"}}}, "ep_mode"),
+        ({"models": {"default": {"preset": "tiny-llama", "kv_fraction": 1.5}}}, "kv_fraction"),
+    ):
+        with pytest.raises(ValueError, match=word):
+            config_from_dict(bad)

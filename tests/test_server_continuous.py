@@ -206,7 +206,7 @@ def test_a_request_that_times_out_is_answered_504_and_cancelled():
                             "sampling": {"temperature": 0.0, "max_new_tokens": 400},
                             "models": {"default": {"preset": "tiny-llama", "seed": 1, "kv_blocks": 512}}})
     ens = build_ensemble(cfg)
-    srv = ConsensusServer(ens, port=0, max_batch=8, request_timeout_s=1.0).start()
+    srv = ConsensusServer(ens, port=0, max_batch=8, request_timeout_s=0.2).start()       # 400 tokens take ~1 s here
     eng = next(iter(ens.backends.values())).engine
     model = next(iter(ens.backends))
     try:
