@@ -17,7 +17,8 @@ Time budget on a multi-GPU node (defaults): A, B and C take ~180 s (C with 32 qu
 flight and four timed steps); the sections that run in child processes (A with one model per
 GPU, D, E) share ``--isolated-budget`` 360 s, each attempt at most ``--section-timeout`` 150 s,
 and an attempt is only started with a minute left: the whole run stays under 180 + 360 = 540 s
-whatever stalls. A model group's own collectives give
+whatever stalls; ``--wall-budget`` 570 s (counted from process start, so a slow start on a cold
+machine is seen too) ends or skips child sections all the same. A model group's own collectives give
 up waiting for a peer after LC_P2P_TIMEOUT_S (10 s here) and a group whose first exchange fails
 its self-check falls back to RCCL inside the same process (parallel/p2p.py).
 
@@ -118,6 +119,10 @@ def parse_args(argv=None):
     ap.add_argument("--isolated-budget", type=float, default=360.0,
                     help="multi-GPU runs: seconds all child-process sections together may take; what is left "
                          "bounds each attempt, and a section that finds less than a minute left is skipped")
+    ap.add_argument("--wall-budget", type=float, default=570.0,
+                    help="multi-GPU runs: seconds since this process started (imports and model loading included) "
+                         "after which no child-process section is started or kept running; guards the run against "
+                         "a slow start on a cold machine, which --isolated-budget alone does not see")
     ap.add_argument("--share-gpu", action="store_true",
                     help="rehearsal on a one-GPU machine: all --gpus ranks use GPU 0, the process group is gloo with "
                          "host-staged tensors (RCCL refuses two ranks on one device), model groups still use the "
@@ -694,9 +699,11 @@ def run_isolated(ctx: Ctx, a, argv, letter: str, extra_args=(), pick=None):
         attempts = attempts[1:]                    # an earlier section already found that path unusable here
     for label, extra in attempts:
         # rank 0's clock decides for everybody, so that all ranks take the same branch
-        left = ctx.comm.broadcast_object(a.isolated_budget - getattr(ctx, "isolated_spent", 0.0) if lead else None, 0)
+        left = ctx.comm.broadcast_object(
+            min(a.isolated_budget - getattr(ctx, "isolated_spent", 0.0), a.wall_budget - (time.perf_counter() - T_START))
+            if lead else None, 0)
         if left < 60.0:
-            errors.append([f"{label}: skipped, {left:.0f} s of --isolated-budget left"])
+            errors.append([f"{label}: skipped, {left:.0f} s left of --isolated-budget / --wall-budget"])
             break
         t_attempt = time.perf_counter()
         limit = min(a.section_timeout, left)

@@ -129,6 +129,15 @@ def test_isolated_sections_share_one_time_budget():
         assert "skipped" in json.dumps(out[key]["error"]), out[key]
 
 
+def test_wall_budget_counts_from_process_start():
+    """--wall-budget is measured from the start of the process (imports, model loading and the
+    replica workloads included): with less than a minute of it left no child section is started."""
+    p = run_bench(["--gpus", "2", "--workload", "A,D", "--wall-budget", "20", "--skip-spread"] + TINY)
+    assert p.returncode == 0, p.stderr[-3000:]
+    out = json_line(p)
+    assert out["value"] > 0 and "wall-budget" in json.dumps(out["judge_consensus"]["error"])
+
+
 def test_isolated_section_reports_which_collectives_it_used():
     p = run_bench(["--gpus", "2", "--workload", "E"] + TINY)
     assert p.returncode == 0, p.stderr[-3000:]
