@@ -383,3 +383,19 @@ def test_lockstep_driver_shards_tickets_over_replicas():
     res = run_loopback(6, lambda comm: _lockstep_serve(comm, cfg, QUESTIONS, [0, 0, 1, 1, 4, 4][:len(QUESTIONS)]
                                                        + [6] * max(0, len(QUESTIONS) - 6)))
     assert [res[0][i] for i in range(len(QUESTIONS))] == want
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_lockstep_driver_random_arrivals_equal_the_wave_driver(seed):
+    """Questions arriving in random rounds (bursts, gaps, everything at once), over one replica of
+    three ranks or two replicas of three: every answer is the wave driver's."""
+    from llm_consensus_amd.app import build_ensemble
+
+    rng = np.random.default_rng(40 + seed)
+    cfg = _spread_cfg()
+    qs = [QUESTIONS[i % len(QUESTIONS)] + f" (variant {i})" for i in range(int(rng.integers(4, 10)))]
+    want = [r.answer for r in build_ensemble(cfg, torch.device("cpu")).ask_many(qs)]
+    arrivals = [int(a) for a in rng.integers(0, int(rng.choice([1, 6, 25])) + 1, size=len(qs))]
+    ranks = int(rng.choice([3, 6]))
+    res = run_loopback(ranks, lambda comm: _lockstep_serve(comm, cfg, qs, arrivals))
+    assert [res[0][i] for i in range(len(qs))] == want, (arrivals, ranks)
