@@ -555,7 +555,7 @@ class ConsensusServer:
                                                         if e.status < 500 else "server_error", "code": e.status}})
             except (BrokenPipeError, ConnectionResetError):
                 pass                     # the client this error is for has gone (status 499 always ends here)
-        except (BrokenPipeError, ConnectionResetError, TimeoutError):
+        except OSError:
             h.close_connection = True            # the client went away, or stopped sending / reading
         finally:
             with self._lock:
@@ -729,7 +729,7 @@ class ConsensusServer:
         deadline = time.perf_counter() + self.request_timeout_s
         try:
             self._stream_tokens_body(h, job, emit, started, deadline, chat)
-        except (BrokenPipeError, ConnectionResetError):
+        except OSError:                 # reset, broken pipe, or a reader so slow that a write timed out
             self._cancel(job)           # nobody reads the stream any more: stop generating
             raise
 

@@ -450,3 +450,46 @@ def test_malformed_and_stalling_requests_cost_the_server_nothing():
         assert threading.active_count() < 20          # no handler threads left behind
     finally:
         srv.shutdown()
+
+
+def test_a_stream_reader_that_stalls_is_cut_off_and_its_work_cancelled(monkeypatch):
+    """A client that asks for a token stream and then stops reading: once the socket buffers are
+    full a write times out (io_timeout_s). The request is cancelled and the engine lets it go; the
+    server keeps answering others. (Loopback buffers hold more than a tiny model's context can
+    produce, so the timed-out write is injected at the first chunk.)"""
+    cfg = config_from_dict({"strategy": "majority_vote", "sampling": {"temperature": 0.0, "max_new_tokens": 4},
+                            "models": {"default": {"preset": "tiny-llama", "seed": 1, "kv_blocks": 512}},
+                            "members": [{"name": "a", "model": "default"}]})
+    ens = build_ensemble(cfg)
+    srv = ConsensusServer(ens, port=0).start()
+    eng = ens.backends["default"].engine
+    real = ConsensusServer._stream_tokens_body
+
+    def stalled(self, h, job, emit, started, deadline, chat):
+        item = job.chunks.get(timeout=30)            # generation is under way
+        assert item is not None
+        raise TimeoutError("timed out")              # what socket.sendall raises when the reader has stalled
+
+    monkeypatch.setattr(ConsensusServer, "_stream_tokens_body", stalled)
+    try:
+        req = urllib.request.Request(f"http://127.0.0.1:{srv.port}/v1/completions",
+                                     json.dumps({"model": "default", "prompt": "tell me everything", "max_tokens": 400,
+                                                 "stream": True}).encode(), {"Content-Type": "application/json"})
+        try:
+            urllib.request.urlopen(req, timeout=60).read()
+        except Exception:  # noqa: BLE001  the connection is cut; how the client sees that does not matter here
+            pass
+        deadline = time.time() + 30
+        while time.time() < deadline and eng.stats().get("requests.cancelled", 0) < 1:
+            time.sleep(0.05)
+        st = eng.stats()
+        assert st.get("requests.cancelled", 0) == 1 and st["decode.tokens"] < 400, st
+        monkeypatch.setattr(ConsensusServer, "_stream_tokens_body", real)
+        code, out = _post(srv.port, "/v1/completions", {"model": "default", "prompt": "and you?", "max_tokens": 2})
+        assert code == 200
+        deadline = time.time() + 20
+        while time.time() < deadline and eng.stats()["sched.running"]:
+            time.sleep(0.05)
+        assert eng.stats()["sched.running"] == 0
+    finally:
+        srv.shutdown()
