@@ -824,17 +824,24 @@ class ConsensusServer:
         inputs = [inp] if isinstance(inp, str) else inp
         if not isinstance(inputs, list) or not inputs or not all(isinstance(x, str) and x for x in inputs):
             raise HTTPError(400, "'input' must be a non-empty string or list of strings")
+        if len(inputs) > 256:
+            raise HTTPError(400, "at most 256 inputs per embeddings request")
         jobs = [_Job("embed", model, x) for x in inputs]
         for j in jobs[:-1]:
             self.jobs.put(j)
-        self.submit(jobs[-1])
-        data = []
-        for i, j in enumerate(jobs):
-            if not j.done.wait(self.request_timeout_s):
-                raise HTTPError(504, "request timed out in the engine queue")
-            if j.error:
-                raise HTTPError(500, j.error)
-            data.append({"object": "embedding", "index": i, "embedding": [float(x) for x in j.result]})
+        try:
+            self.submit(jobs[-1], h.connection)
+            data = []
+            for i, j in enumerate(jobs):
+                if not j.done.wait(self.request_timeout_s):
+                    raise HTTPError(504, "request timed out in the engine queue")
+                if j.error:
+                    raise HTTPError(500, j.error)
+                data.append({"object": "embedding", "index": i, "embedding": [float(x) for x in j.result]})
+        except HTTPError:
+            for j in jobs:              # the caller is gone or out of time: none of its inputs is worth computing
+                self._cancel(j)
+            raise
         self._send_json(h, 200, {"object": "list", "data": data, "model": model,
                                  "usage": {"prompt_tokens": 0, "total_tokens": 0}})
 
