@@ -154,3 +154,63 @@ def test_token_level_decisions_in_the_vote_strategies():
     one = [Member(personas[0], Canned(["Answer:D then C", "Answer: C then:D"]), params=gp)]
     res = MajorityVote(one, decision_mode="tokens", cue_window=12).ask_many(["q0", "q1"])
     assert [r.votes[0]["class"] for r in res] == [3, 2]
+
+
+@settings(max_examples=150, deadline=None, derandomize=True)
+@given(st.integers(2, 9), st.integers(2, 24), st.integers(0, 10_000))
+def test_medoid_matches_numpy(n, d, seed):
+    rng = np.random.default_rng(seed)
+    E = rng.normal(size=(n, d)).astype(np.float32)
+    r = reducers.cosine_medoid(E)
+    U = E / np.linalg.norm(E, axis=1, keepdims=True)
+    s = (U @ U.T).sum(1) - 1.0
+    assert 0 <= r.index < n and s[r.index] >= s.max() - 1e-4          # ties may go either way
+    assert abs(r.score - s[r.index] / (n - 1)) < 1e-4
+
+
+@settings(max_examples=150, deadline=None, derandomize=True)
+@given(st.integers(1, 5), st.integers(1, 6), st.integers(1, 4), st.integers(0, 10_000))
+def test_judge_reduce_matches_numpy(q, c, j, seed):
+    rng = np.random.default_rng(seed)
+    s = rng.normal(size=(q, c, j)).astype(np.float32)             # [question, candidate, judge]
+    out = reducers.judge_reduce_batch(s)
+    mean = s.mean(2)
+    for i in range(q):
+        assert mean[i, out.winner[i]] >= mean[i].max() - 1e-5
+        assert abs(out.score[i] - mean[i, out.winner[i]]) < 1e-5
+        assert bool(out.unanimous[i]) == bool((s[i].argmax(0) == out.winner[i]).all()) or c == 1
+
+
+@settings(max_examples=150, deadline=None, derandomize=True)
+@given(st.lists(st.tuples(st.floats(-20, 0), st.floats(-20, 0)), min_size=1, max_size=8))
+def test_unanimity_matches_its_definition(rows):
+    lp = np.array(rows, dtype=np.float32)                          # [member, (Good, NeedsRefinement)]
+    u = reducers.unanimity(lp)
+    dissent = [i for i in range(len(rows)) if lp[i, 1] > lp[i, 0]]
+    assert u.dissenters == dissent and u.all_good == (not dissent)
+
+
+@settings(max_examples=200, deadline=None, derandomize=True)
+@given(st.lists(st.lists(st.integers(0, 9), min_size=1, max_size=24), min_size=1, max_size=6),
+       st.lists(st.integers(0, 9), min_size=0, max_size=3), st.integers(1, 6))
+def test_answer_extract_matches_a_python_scan(rows, marker, window):
+    choices = [3, 7, 8]
+    L = max(len(r) for r in rows)
+    ids = np.zeros((len(rows), L), dtype=np.int32)
+    lens = np.array([len(r) for r in rows], dtype=np.int32)
+    for i, r in enumerate(rows):
+        ids[i, :len(r)] = r
+    got = reducers.answer_extract(ids, lens, marker, choices, window=window).tolist()
+    for i, r in enumerate(rows):
+        start = 0
+        if marker:
+            hits = [k for k in range(len(r) - len(marker) + 1) if r[k:k + len(marker)] == marker]
+            if not hits:
+                assert got[i] == -1
+                continue
+            start = hits[-1] + len(marker)
+            span = r[start:start + window]
+            want = next((choices.index(t) for t in span if t in choices), -1)
+        else:                                                       # no cue: the LAST choice token anywhere
+            want = next((choices.index(t) for t in reversed(r) if t in choices), -1)
+        assert got[i] == want, (r, marker, window)
