@@ -131,6 +131,17 @@ class TransformerModel:
         r, tp = self.tp_rank, self.tp_size
         Dh = c.head_dim
         bf = lambda t: t.to(torch.bfloat16)  # noqa: E731
+        source = get
+
+        def get(name: str):
+            # A checkpoint whose tensors do not have the shapes its config.json implies (another
+            # model's file, a truncated conversion) must fail here, by name: sliced and packed it
+            # would load, and a GEMM would then read a weight of the wrong depth.
+            t = source(name)
+            want = tuple(hf_param_shape(c, name))
+            if tuple(t.shape) != want:
+                raise ValueError(f"{c.name}: tensor {name!r} has shape {tuple(t.shape)}, the configuration implies {want}")
+            return t
         self.embed = bf(get("model.embed_tokens.weight")).to(dev).contiguous()
         self.final_norm = bf(get("model.norm.weight")).to(dev).contiguous()
         lm = get("model.embed_tokens.weight") if c.tie_embeddings else get("lm_head.weight")

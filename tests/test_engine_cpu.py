@@ -433,3 +433,26 @@ def test_backend_streams_and_stop_sequences_under_random_traffic(seed):
             assert [list(t) for t in res.token_ids] != [list(t)[:len(g)] for t, g in zip(r["full_ids"], res.token_ids)], \
                 (stops, res.texts, want)
     assert drifted <= max(2, len(reqs) // 6), drifted
+
+
+def test_checkpoint_tensors_must_have_the_shapes_the_config_implies(ckpts, tmp_path):
+    """A tensor of the wrong shape (another model's file, a truncated conversion) is refused by
+    name at load time instead of being sliced, packed and multiplied."""
+    import json
+    import shutil
+    from pathlib import Path
+
+    from safetensors.torch import load_file, save_file
+
+    src = Path(ckpts["tiny-llama"])
+    bad = tmp_path / "bad"
+    shutil.copytree(src, bad)
+    f = next(bad.glob("*.safetensors"))
+    t = load_file(str(f))
+    name = "model.layers.0.mlp.down_proj.weight"
+    t[name] = t[name][:, :-16].contiguous()
+    save_file(t, str(f))
+    with pytest.raises(ValueError, match="down_proj.*configuration implies"):
+        load_model(str(bad), "cpu")
+    json.loads((bad / "config.json").read_text())          # (the config itself is fine)
+    assert load_model(str(src), "cpu") is not None
