@@ -650,6 +650,13 @@ class Engine:
         ids = np.asarray(prompt_ids, dtype=np.int32)
         if ids.size == 0:
             raise ValueError("empty prompt")
+        vocab = self.model.cfg.vocab_size
+        for what, arr in (("prompt", ids), ("decision target", decision_ids), ("score target", score_ids)):
+            if arr is not None and len(arr) and (min(arr) < 0 or max(arr) >= vocab):
+                # (the kernels clamp such ids rather than read outside the table: the answer would be
+                # wrong without a trace. A tokenizer that does not belong to the model is the usual cause.)
+                raise ValueError(f"{what} token id outside the model's vocabulary of {vocab}: "
+                                 f"{int(min(arr))} .. {int(max(arr))}")
         budget = self.max_model_len - (p.max_new_tokens if kind == core.RequestKind.Generate else 0)
         if ids.size > budget:
             ids = ids[-budget:]  # keep the tail (the instructions and the answer slot are at the end)

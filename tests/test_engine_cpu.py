@@ -456,3 +456,17 @@ def test_checkpoint_tensors_must_have_the_shapes_the_config_implies(ckpts, tmp_p
         load_model(str(bad), "cpu")
     json.loads((bad / "config.json").read_text())          # (the config itself is fine)
     assert load_model(str(src), "cpu") is not None
+
+
+def test_token_ids_outside_the_vocabulary_are_refused():
+    cfg = get_preset("tiny-llama")
+    eng = Engine(TransformerModel.random_init(cfg, "cpu", seed=1), num_kv_blocks=32, block_size=16, use_graphs=False)
+    for kw in (dict(prompt_ids=[1, 2, cfg.vocab_size]), dict(prompt_ids=[-1, 2]),
+               dict(prompt_ids=[1, 2], decision_ids=[3, cfg.vocab_size + 5]),
+               dict(prompt_ids=[1, 2], kind=core.RequestKind.Score, score_ids=[-2])):
+        with pytest.raises(ValueError, match="vocabulary"):
+            eng.submit(**kw)
+    assert not eng.has_work()
+    rid = eng.submit([1, 2, cfg.vocab_size - 1], params=greedy_params(2), decision_ids=[0, cfg.vocab_size - 1])
+    eng.run_until_done()
+    assert len(eng.pop_result(rid).token_ids[0]) == 2
