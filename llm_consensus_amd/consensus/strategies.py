@@ -592,18 +592,32 @@ class EmbeddingMedoid:
     def _finish(self, questions: Sequence[str], states: Sequence[dict], t0s: Sequence[float]) -> List[ConsensusResult]:
         out = []
         for q, st, t0 in zip(questions, states, t0s):
-            if not st["cands"]:
-                out.append(ConsensusResult(question=q, answer="", strategy=self.name, extra={"error": "no candidates"}))
+            # a candidate whose embedding call failed leaves the vote, like a proposer whose call failed
+            cands, owners, rows = [], [], []
+            for c, o, h in zip(st["cands"], st["owners"], st["emb"]):
+                try:
+                    rows.append(np.asarray(h.result(), dtype=np.float32))
+                    cands.append(c)
+                    owners.append(o)
+                except BackendError as e:
+                    log.error("%s failed to embed a candidate of %s: %s", self.embedder.name, o, e)
+            if not cands:
+                why = "no candidates" if not st["cands"] else "no candidate could be embedded"
+                out.append(ConsensusResult(question=q, answer="", strategy=self.name, extra={"error": why},
+                                           usage=add_usage({}, list(st["prop"]) + list(st["emb"]))))
                 continue
-            E = np.stack([np.asarray(h.result(), dtype=np.float32) for h in st["emb"]])
-            red = reducers.cosine_medoid(E, device=self.device)
+            if len(cands) == 1:
+                idx, score, pairwise = 0, 1.0, 1.0          # nothing to compare the survivor with
+            else:
+                red = reducers.cosine_medoid(np.stack(rows), device=self.device)
+                idx, score, pairwise = int(red.index), float(red.score), float(red.mean_pairwise)
             done = max((h.finished_at or t0) for h in st["emb"])
             out.append(ConsensusResult(
-                question=q, answer=st["cands"][red.index], strategy=self.name, rounds=1,
-                member_calls=len(self.proposers) + len(st["cands"]), proposer=st["owners"][red.index],
-                latency_s=(done - t0) if done > t0 else time.perf_counter() - t0, agreement=float(red.mean_pairwise),
-                votes=[{"candidate": st["owners"][i], "text": c} for i, c in enumerate(st["cands"])],
-                extra={"medoid_score": float(red.score)},
+                question=q, answer=cands[idx], strategy=self.name, rounds=1,
+                member_calls=len(self.proposers) + len(st["cands"]), proposer=owners[idx],
+                latency_s=(done - t0) if done > t0 else time.perf_counter() - t0, agreement=pairwise,
+                votes=[{"candidate": owners[i], "text": c} for i, c in enumerate(cands)],
+                extra={"medoid_score": score},
                 usage=add_usage({}, list(st["prop"]) + list(st["emb"])),
             ))
         return out

@@ -193,3 +193,34 @@ def test_two_phase_strategies_without_batch_boundaries(strategy):
             got[tickets[t]] = (r.answer, r.proposer)
     assert got == want
     assert pool.drain() == []
+
+
+def test_embedding_medoid_drops_candidates_whose_embedding_failed():
+    """A failed embedding call removes that candidate from the vote (batch driver and pool alike);
+    only a question none of whose candidates could be embedded comes back empty, with the reason."""
+    from llm_consensus_amd._native import core
+    from llm_consensus_amd.consensus.backend import GenParams, ScriptedBackend
+    from llm_consensus_amd.consensus.members import Member
+    from llm_consensus_amd.consensus.strategies import EmbeddingMedoid
+
+    P = core.default_personas()
+
+    def strategy(embed_fail_every):
+        gen = ScriptedBackend({"propose": lambda p: "candidate text"}, name="gen")
+        emb = ScriptedBackend(fail_every=embed_fail_every, name="emb")
+        props = [Member(P[i], gen, params=GenParams(max_new_tokens=4)) for i in range(3)]
+        return EmbeddingMedoid(props, Member(P[3], emb, params=GenParams(max_new_tokens=4), role="embedder"))
+
+    for run in (lambda s, qs: s.ask_many(qs), lambda s, qs: [r for _, r in sorted(_pool_drain(s, qs))]):
+        res = run(strategy(2), ["q one", "q two"])                  # every second embedding fails
+        assert [r.answer for r in res] == ["candidate text"] * 2
+        assert all(1 <= len(r.votes) < 3 for r in res)
+        res = run(strategy(1), ["q one"])                            # all of them fail
+        assert res[0].answer == "" and "embedded" in res[0].extra["error"]
+
+
+def _pool_drain(strategy, questions):
+    pool = strategy.pool()
+    for q in questions:
+        pool.submit(q)
+    return pool.drain()
