@@ -224,6 +224,10 @@ class MajorityVote:
                        for i, m in enumerate(self.members)],
                 usage=add_usage({}, handles[r]),
             ))
+            if all(x is None for x in results[r]):
+                out[-1].extra["error"] = "every member call failed"
+            elif w < 0:
+                out[-1].extra["error"] = "no reply contained a choice"
         return out
 
     def ask_many(self, questions: Sequence[str]) -> List[ConsensusResult]:
@@ -386,6 +390,10 @@ class SelfConsistency:
                 extra={"cached_prompt_tokens": cached[r], "chains": chains_text[r]},
                 usage=add_usage({}, handles[r]),
             ))
+            if results[r] is None:
+                out[-1].extra["error"] = "the member call failed"
+            elif w < 0:
+                out[-1].extra["error"] = "no chain produced an answer"
         return out
 
     def ask_many(self, questions: Sequence[str]) -> List[ConsensusResult]:
