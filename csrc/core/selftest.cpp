@@ -265,7 +265,7 @@ int main(int argc, char** argv) {
     pool.emplace_back([&, t] {
       forced[t] = run_sessions(1000 + t, 300 * scale, &metrics);
       run_scheduler(2000 + t, 150 * scale, &metrics);
-      for (int k = 0; k < 40 * scale; ++k) run_scheduler_hard(3000 + 100 * t + k, 60, &metrics);
+      for (int k = 0; k < 12 * scale; ++k) run_scheduler_hard(3000 + 100 * t + k, 60, &metrics);
     });
   for (auto& th : pool) th.join();
   CHECK(metrics.counter("sessions") == 300.0 * scale * threads);
