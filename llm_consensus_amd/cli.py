@@ -22,10 +22,11 @@ from __future__ import annotations
 
 import argparse
 import json
+import os
 import sys
 from typing import Iterable, Optional, TextIO
 
-from .config import ConsensusConfig, load_config
+from .config import ConsensusConfig, load_config, load_config_or_exit  # noqa: F401  (load_config: re-exported)
 from .utils.log import get_logger
 
 PROMPT = "Enter a question: "
@@ -109,7 +110,11 @@ def main(argv: Optional[list] = None) -> int:
     argv = sys.argv[1:] if argv is None else list(argv)
     args = ap.parse_args(argv)
 
-    cfg: ConsensusConfig = load_config(args.config)
+    cfg: ConsensusConfig = load_config_or_exit(args.config, "llm-consensus")
+    if args.questions and not os.access(args.questions, os.R_OK):
+        # (before any model is loaded: the file is read after the ensemble is up)
+        print(f"llm-consensus: error: cannot read --questions {args.questions}", file=sys.stderr, flush=True)
+        return 2
     random_init = sorted({m.model for m in cfg.members if not cfg.models[m.model].path})
     if random_init:
         # The reference refuses to start without a usable backend (main.rs:354-357). Random
@@ -120,7 +125,11 @@ def main(argv: Optional[list] = None) -> int:
         print(msg, file=sys.stderr, flush=True)
     if args.strategy:
         cfg.strategy = args.strategy
-        cfg.validate()
+        try:
+            cfg.validate()
+        except ValueError as e:
+            print(f"llm-consensus: error: --strategy: {e}", file=sys.stderr, flush=True)
+            return 2
     from .parallel import launch
 
     if not args.distributed and not launch.under_launcher():

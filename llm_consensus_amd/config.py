@@ -260,6 +260,19 @@ def config_from_dict(d: Dict[str, Any]) -> ConsensusConfig:
     return _build(ConsensusConfig, d)
 
 
+def load_config_or_exit(path: Optional[str], prog: str) -> ConsensusConfig:
+    """``load_config`` for a command line: a missing or malformed file, or a value the checks
+    refuse, ends the command with one line on stderr and status 2 (no traceback, nothing loaded)."""
+    import sys
+
+    try:
+        return load_config(path)
+    except (OSError, ValueError, KeyError, TypeError) as e:      # TOML / JSON / YAML errors are ValueErrors
+        print(f"{prog}: error: configuration {path or os.environ.get('CONSENSUS_CONFIG') or '(defaults)'}: {e}",
+              file=sys.stderr, flush=True)
+        raise SystemExit(2)
+
+
 def load_config(path: Optional[str] = None) -> ConsensusConfig:
     """Loads a config file; ``None`` consults ``$CONSENSUS_CONFIG`` and falls back to
     the reference-equivalent defaults."""

@@ -850,7 +850,7 @@ def main(argv: Optional[list] = None) -> int:
     import argparse
 
     from ..app import build_ensemble
-    from ..config import load_config
+    from ..config import load_config_or_exit
 
     ap = argparse.ArgumentParser(prog="llm-consensus-serve", description="OpenAI-compatible consensus endpoint")
     ap.add_argument("--config")
@@ -884,7 +884,7 @@ def main(argv: Optional[list] = None) -> int:
 
     argv = sys.argv[1:] if argv is None else list(argv)
     args = ap.parse_args(argv)
-    cfg = load_config(args.config)
+    cfg = load_config_or_exit(args.config, "llm-consensus-serve")
     from ..parallel import launch
 
     if not args.distributed and not launch.under_launcher():

@@ -404,3 +404,26 @@ def test_bad_config_values_are_refused_with_a_message_that_names_them():
     ):
         with pytest.raises(ValueError, match=word):
             config_from_dict(bad)
+
+
+def test_command_line_mistakes_end_with_one_line_and_status_2(tmp_path, capsys):
+    """A missing or malformed config, a value the checks refuse, an unreadable --questions file: one
+    line on stderr, exit status 2, and no model is loaded for it."""
+    from llm_consensus_amd import cli
+    from llm_consensus_amd.serve import server
+
+    bad = tmp_path / "bad.toml"
+    bad.write_text('strategy = "nonsense"\n')
+    broken = tmp_path / "broken.toml"
+    broken.write_text("strategy = \n")
+    for argv, word in ((["--config", str(bad)], "unknown strategy"), (["--config", str(broken)], "configuration"),
+                       (["--config", str(tmp_path / "missing.toml")], "No such file")):
+        for main in (cli.main, server.main):
+            with pytest.raises(SystemExit) as e:
+                main(argv + ["--device", "cpu"])
+            assert e.value.code == 2
+            err = capsys.readouterr().err
+            assert word in err and "Traceback" not in err and len(err.strip().splitlines()) == 1
+    assert cli.main(["--device", "cpu", "--questions", str(tmp_path / "none.txt")]) == 2
+    assert "cannot read --questions" in capsys.readouterr().err
+    assert cli.main(["--device", "cpu", "--strategy", "nope"]) == 2
