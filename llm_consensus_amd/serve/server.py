@@ -885,6 +885,17 @@ def main(argv: Optional[list] = None) -> int:
     argv = sys.argv[1:] if argv is None else list(argv)
     args = ap.parse_args(argv)
     cfg = load_config_or_exit(args.config, "llm-consensus-serve")
+    if args.port and int(os.environ.get("RANK", "0")) == 0:
+        # an address that cannot be bound is found out now, not after minutes of model loading
+        probe = socket.socket(socket.AF_INET6 if ":" in args.host else socket.AF_INET)
+        try:
+            probe.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+            probe.bind((args.host, args.port))
+        except OSError as e:
+            print(f"llm-consensus-serve: error: cannot listen on {args.host}:{args.port}: {e}", file=sys.stderr, flush=True)
+            return 2
+        finally:
+            probe.close()
     from ..parallel import launch
 
     if not args.distributed and not launch.under_launcher():

@@ -427,3 +427,17 @@ def test_command_line_mistakes_end_with_one_line_and_status_2(tmp_path, capsys):
     assert cli.main(["--device", "cpu", "--questions", str(tmp_path / "none.txt")]) == 2
     assert "cannot read --questions" in capsys.readouterr().err
     assert cli.main(["--device", "cpu", "--strategy", "nope"]) == 2
+
+
+def test_server_finds_out_that_its_port_is_taken_before_loading_anything(capsys):
+    import socket
+    import time
+
+    from llm_consensus_amd.serve import server
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        s.listen(1)
+        t0 = time.perf_counter()
+        assert server.main(["--device", "cpu", "--port", str(s.getsockname()[1])]) == 2
+        assert "cannot listen" in capsys.readouterr().err and time.perf_counter() - t0 < 2.0
