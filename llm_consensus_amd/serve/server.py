@@ -557,6 +557,15 @@ class ConsensusServer:
                 pass                     # the client this error is for has gone (status 499 always ends here)
         except OSError:
             h.close_connection = True            # the client went away, or stopped sending / reading
+        except Exception as e:  # noqa: BLE001  a bug in a handler must not cost the client its answer line
+            log.error("request %s %s failed: %s: %s", method, h.path, type(e).__name__, e, exc_info=e)
+            with self._lock:
+                self.counters["errors_total"] += 1
+            h.close_connection = True
+            try:
+                self._send_json(h, 500, {"error": {"message": f"{type(e).__name__}: {e}", "type": "server_error", "code": 500}})
+            except OSError:
+                pass
         finally:
             with self._lock:
                 self.counters["latency_seconds_sum"] += time.perf_counter() - t0
@@ -607,30 +616,49 @@ class ConsensusServer:
         if dt is not None and (not isinstance(dt, list) or not dt or len(dt) > 64
                                or not all(isinstance(t, str) and t for t in dt)):
             raise HTTPError(400, "'decision_targets' must be a list of 1-64 non-empty strings")
-        try:
-            return GenParams(
-                decision_targets=dt,
-                stop=stop or None,
-                temperature=float(body.get("temperature", s.temperature)),
-                top_p=float(body.get("top_p", s.top_p)),
-                top_k=int(body.get("top_k", s.top_k)),
-                max_new_tokens=int(mt if mt is not None else s.max_new_tokens),
-                seed=int(body.get("seed", s.seed)),
-                n=int(body.get("n", 1)),
-            )
-        except (TypeError, ValueError) as e:
-            raise HTTPError(400, f"bad sampling parameter: {e}")
+        def number(name, default, lo, hi, integer=False, lo_open=False):
+            v = body.get(name)
+            if v is None:
+                return default
+            ok = isinstance(v, int) and not isinstance(v, bool) if integer else \
+                isinstance(v, (int, float)) and not isinstance(v, bool)
+            if not ok or v != v or v > hi or v < lo or (lo_open and v == lo):
+                kind = "an integer" if integer else "a number"
+                raise HTTPError(400, f"'{name}' must be {kind} in {'(' if lo_open else '['}{lo}, {hi}], not {v!r}")
+            return v
+
+        if mt is not None and (not isinstance(mt, int) or isinstance(mt, bool)):
+            raise HTTPError(400, f"'max_tokens' must be an integer, not {mt!r}")
+        return GenParams(
+            decision_targets=dt,
+            stop=stop or None,
+            temperature=float(number("temperature", s.temperature, 0, 100)),
+            top_p=float(number("top_p", s.top_p, 0, 1, lo_open=True)),
+            top_k=int(number("top_k", s.top_k, 0, 2 ** 31 - 1, integer=True)),
+            max_new_tokens=int(mt if mt is not None else s.max_new_tokens),
+            seed=int(number("seed", s.seed, 0, 2 ** 62, integer=True)),
+            n=int(number("n", 1, 1, 64, integer=True)),
+        )
 
     @staticmethod
     def _chat_text(messages: List[Dict[str, Any]], consensus: bool) -> str:
         if not isinstance(messages, list) or not messages:
             raise HTTPError(400, "'messages' must be a non-empty list")
 
+        if not all(isinstance(m, dict) and isinstance(m.get("role", "user"), str) for m in messages):
+            raise HTTPError(400, "every message must be an object with a string 'role'")
+
         def content(m):
             c = m.get("content", "")
             if isinstance(c, list):  # content parts
-                c = "".join(p.get("text", "") for p in c if isinstance(p, dict))
-            return str(c)
+                if not all(isinstance(p, dict) and isinstance(p.get("text", ""), str) for p in c):
+                    raise HTTPError(400, "content parts must be objects with a string 'text'")
+                c = "".join(p.get("text", "") for p in c)
+            if c is None:
+                c = ""
+            if not isinstance(c, str):
+                raise HTTPError(400, "'content' must be a string or a list of text parts")
+            return c
 
         if consensus:  # the strategy wraps the question in its own prompts
             users = [m for m in messages if m.get("role") == "user"]
@@ -641,6 +669,8 @@ class ConsensusServer:
 
     def _completion(self, h, body: Dict[str, Any], chat: bool) -> None:
         model = body.get("model") or CONSENSUS_MODEL
+        if not isinstance(model, str):
+            raise HTTPError(400, "'model' must be a string")
         consensus = model == CONSENSUS_MODEL
         if not consensus and model not in self.ensemble.backends:
             raise HTTPError(404, f"unknown model {model!r}")
@@ -654,6 +684,8 @@ class ConsensusServer:
                 text = text[0]
             if not isinstance(text, str) or not text:
                 raise HTTPError(400, "'prompt' must be a non-empty string")
+        if body.get("stream") is not None and not isinstance(body.get("stream"), bool):
+            raise HTTPError(400, "'stream' must be true or false")
         params = self._gen_params(body)
         if params.max_new_tokens < 1 or params.n < 1:
             raise HTTPError(400, "'max_tokens' and 'n' must be at least 1")
@@ -801,6 +833,8 @@ class ConsensusServer:
         constrained decision the strategies take on the device (verdict words, choice letters,
         /root/reference/src/main.rs:144-148 parses them out of free text instead)."""
         model = body.get("model")
+        if not isinstance(model, str):
+            raise HTTPError(400, "'model' must be a string")
         if model not in self.ensemble.backends:
             raise HTTPError(404, f"unknown model {model!r}")
         prompt, targets = body.get("prompt"), body.get("targets")
@@ -815,6 +849,8 @@ class ConsensusServer:
 
     def _embeddings(self, h, body: Dict[str, Any]) -> None:
         model = body.get("model")
+        if model is not None and not isinstance(model, str):
+            raise HTTPError(400, "'model' must be a string")
         if not model or model == CONSENSUS_MODEL:
             emb = [m for m in self.ensemble.members if m.role == "embedder"] or self.ensemble.members
             model = next(k for k, b in self.ensemble.backends.items() if b is emb[0].backend)

@@ -493,3 +493,44 @@ def test_a_stream_reader_that_stalls_is_cut_off_and_its_work_cancelled(monkeypat
         assert eng.stats()["sched.running"] == 0
     finally:
         srv.shutdown()
+
+
+def test_wrongly_typed_fields_get_400_never_a_dropped_connection():
+    """Every field of every POST route set to values of the wrong type or range (null, numbers,
+    strings, lists, objects, booleans, huge integers): the answer is 200, 400 or 404 with a JSON
+    body; no request costs the client its connection or the server a handler thread."""
+    cfg = config_from_dict({"strategy": "majority_vote", "sampling": {"temperature": 0.0, "max_new_tokens": 2},
+                            "models": {"default": {"preset": "tiny-llama", "seed": 1}},
+                            "members": [{"name": "a", "model": "default"}]})
+    srv = ConsensusServer(build_ensemble(cfg), port=0, request_timeout_s=30).start()
+
+    def post(path, body):
+        req = urllib.request.Request(f"http://127.0.0.1:{srv.port}{path}", json.dumps(body).encode(),
+                                     {"Content-Type": "application/json"})
+        try:
+            with urllib.request.urlopen(req, timeout=60) as r:
+                r.read()                      # JSON, or server-sent events where "stream" happened to be true
+                return r.status
+        except urllib.error.HTTPError as e:
+            assert "error" in json.loads(e.read())
+            return e.code
+
+    weird = [None, 5, -1, 1.5, "x", "", [], [1], {}, {"a": 1}, True, 10 ** 12]
+    try:
+        for path, base, keys in (
+            ("/v1/chat/completions", {"messages": [{"role": "user", "content": "hi"}]},
+             ["messages", "model", "n", "max_tokens", "temperature", "top_p", "top_k", "seed", "stop", "stream"]),
+            ("/v1/completions", {"model": "default", "prompt": "hi", "max_tokens": 2},
+             ["prompt", "model", "n", "max_tokens", "temperature", "top_p", "top_k", "seed", "stop", "stream", "decision_targets"]),
+            ("/v1/embeddings", {"model": "default", "input": "hi"}, ["input", "model"]),
+            ("/v1/score", {"model": "default", "prompt": "hi", "targets": ["a"]}, ["prompt", "targets", "model"]),
+        ):
+            for k in keys:
+                for w in weird:
+                    assert post(path, dict(base, **{k: w})) in (200, 400, 404), (path, k, w)
+        for m in ([1], [{"role": 5, "content": 7}], [{"content": None}], [{"role": "user"}],
+                  [{"role": "user", "content": [{"text": 5}]}], [[]], [{"role": "user", "content": [{"type": "text", "text": "ok"}]}]):
+            assert post("/v1/chat/completions", {"messages": m}) in (200, 400), m
+        assert srv.counters["errors_total"] > 50 and threading.active_count() < 20
+    finally:
+        srv.shutdown()
