@@ -30,6 +30,10 @@ int Scheduler::add_request(RequestKind kind, std::vector<int32_t> prompt, int n_
   g.budget_blocks = P / bs + n_chains * std::max(per_chain, (P % bs) ? 1 : 0);
   if (g.budget_blocks > kv_->stats().blocks_total || n_chains > cfg_.max_batch_seqs)
     throw std::invalid_argument("Scheduler::add_request: request can never fit in the KV pool");
+  // One sequence's block table has a fixed width in the step buffers of the engine: a request whose
+  // prompt + answer would need more blocks is refused here, not found out when a step is packed.
+  if (cfg_.max_blocks_per_seq > 0 && (P + g.p.max_new_tokens + bs - 1) / bs > cfg_.max_blocks_per_seq)
+    throw std::invalid_argument("Scheduler::add_request: prompt + max_new_tokens exceed the longest sequence served");
   int id = g.id;
   groups_.emplace(id, std::move(g));
   waiting_.push_back(id);

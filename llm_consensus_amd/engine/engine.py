@@ -557,9 +557,10 @@ class Engine:
         # never starves the chains that are already generating.
         sc.mix_decode = mix_decode
         sc.optimistic_admission = optimistic_admission
+        self.max_blocks_cap = (self.max_model_len + block_size - 1) // block_size + 1
+        sc.max_blocks_per_seq = self.max_blocks_cap        # the width of a block-table row in the step buffers
         self.sched = core.Scheduler(self.kvm, sc)
         self.max_batch_seqs = max_batch_seqs
-        self.max_blocks_cap = (self.max_model_len + block_size - 1) // block_size + 1
         # Decode graphs are captured per (batch bucket, context class): the number of KV splits
         # and prefix pieces is a launch-time constant, and the right one depends on how long the
         # contexts of the step are. Classes are powers of two from 256 keys up.
@@ -657,7 +658,13 @@ class Engine:
                 # wrong without a trace. A tokenizer that does not belong to the model is the usual cause.)
                 raise ValueError(f"{what} token id outside the model's vocabulary of {vocab}: "
                                  f"{int(min(arr))} .. {int(max(arr))}")
-        budget = self.max_model_len - (p.max_new_tokens if kind == core.RequestKind.Generate else 0)
+        if n < 1:
+            raise ValueError(f"n = {n}: a request has at least one chain")
+        new = p.max_new_tokens if kind == core.RequestKind.Generate else 0
+        if kind == core.RequestKind.Generate and not 1 <= new < self.max_model_len:
+            raise ValueError(f"max_new_tokens = {new} must lie in [1, {self.max_model_len - 1}]: the longest sequence "
+                             f"served is {self.max_model_len} tokens and a prompt has at least one")
+        budget = self.max_model_len - new
         if ids.size > budget:
             ids = ids[-budget:]  # keep the tail (the instructions and the answer slot are at the end)
         if decision_ids is not None and len(decision_ids) > self.max_decision:

@@ -470,3 +470,31 @@ def test_token_ids_outside_the_vocabulary_are_refused():
     rid = eng.submit([1, 2, cfg.vocab_size - 1], params=greedy_params(2), decision_ids=[0, cfg.vocab_size - 1])
     eng.run_until_done()
     assert len(eng.pop_result(rid).token_ids[0]) == 2
+
+
+def test_requests_that_cannot_be_served_are_refused_at_submit_and_leave_the_engine_usable():
+    """max_new_tokens that leaves no room for a prompt (it used to slip through as an untruncated
+    prompt, fail inside a step and wedge the engine), no chains, a prompt + answer longer than a
+    block-table row: all refused at submit; the engine then serves the next request."""
+    cfg = get_preset("tiny-llama")
+    eng = Engine(TransformerModel.random_init(cfg, "cpu", seed=1), num_kv_blocks=32, block_size=16, use_graphs=False,
+                 max_model_len=128)
+    for new in (10000, 128, 0, -4):
+        with pytest.raises(ValueError, match="max_new_tokens"):
+            eng.submit(list(range(5, 25)), params=greedy_params(new))
+    for n in (0, -1):
+        with pytest.raises(ValueError, match="chain"):
+            eng.submit([5, 6, 7], n=n, params=greedy_params(3))
+    assert not eng.has_work()
+    rid = eng.submit(list(range(5, 25)), params=greedy_params(120))      # the prompt keeps its last 8 tokens
+    eng.run_until_done()
+    out = eng.pop_result(rid)
+    assert out.prompt_len == 8 and len(out.token_ids[0]) == 120
+    # the scheduler's own limit (a block-table row of the step buffers)
+    kv = core.KVManager(64, 16, False)
+    sc = core.SchedulerConfig(); sc.max_blocks_per_seq = 4
+    sched = core.Scheduler(kv, sc)
+    p = core.SamplingParams(); p.max_new_tokens = 40
+    with pytest.raises(ValueError, match="longest sequence"):
+        sched.add_request(core.RequestKind.Generate, np.arange(30, dtype=np.int32), 1, p)
+    assert sched.add_request(core.RequestKind.Generate, np.arange(20, dtype=np.int32), 1, p) >= 0
