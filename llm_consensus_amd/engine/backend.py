@@ -70,6 +70,8 @@ class EngineBackend(Backend):
     def submit_score(self, prompt: str, targets: Sequence[str]) -> Handle:
         h = Handle()
         try:
+            if not targets:
+                raise ValueError("no targets to score")
             ids = self.tok.encode(self._wrap(prompt))
             tids = [self.tok.first_token_id(t) for t in targets]
             rid = self.engine.submit(ids, core.RequestKind.Score, score_ids=tids)

@@ -76,6 +76,8 @@ class ByteLevelTokenizer(Tokenizer):
     def first_token_id(self, text: str) -> int:
         # leading spaces carry no signal for a byte tokenizer: " A" and " B" would collide
         s = text.lstrip(" ") or text
+        if not s:
+            raise ValueError("an empty target encodes to nothing")
         return self.encode(s, add_bos=False)[0]
 
 
