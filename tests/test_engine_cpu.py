@@ -238,8 +238,9 @@ def test_backend_handle_cancel_completes_the_handle_with_an_error():
     assert st["kv.blocks_free"] + st["kv.blocks_cached"] == st["kv.blocks_total"] and st["requests.cancelled"] == 1
 
 
-@pytest.mark.parametrize("seed", range(12))
-def test_engine_under_random_traffic_matches_solo_runs(seed):
+@pytest.mark.parametrize("preset", ["tiny-llama", "tiny-mistral", "tiny-qwen", "tiny-mixtral"])
+@pytest.mark.parametrize("seed", range(5))
+def test_engine_under_random_traffic_matches_solo_runs(seed, preset):
     """Random engine settings (mixed steps, optimistic admission with preemption, decode steps
     launched ahead, prefix cache, small KV pools), random arrivals between steps (1-4 chains,
     greedy and sampled, with decision targets, score and embed requests), random cancellations.
@@ -253,7 +254,7 @@ def test_engine_under_random_traffic_matches_solo_runs(seed):
     walk (the draw goes through the vocabulary in index order, a boundary that moved by 1e-3 of
     the mass is a step of an index or two). Anything else is a bug."""
     rng = np.random.default_rng(1000 + seed)
-    cfg = get_preset("tiny-llama")
+    cfg = get_preset(preset)
     model = TransformerModel.random_init(cfg, "cpu", seed=9, std=0.1)
     kw = dict(block_size=16, use_graphs=False, max_model_len=256)
     knobs = dict(num_kv_blocks=int(rng.integers(28, 96)), max_batch_seqs=int(rng.integers(4, 12)),
