@@ -153,8 +153,13 @@ def test_four_ranks_shard_the_judge_four_ways_next_to_the_proposers():
     `tiny-judge` is the smallest preset four ranks can shard (four kv heads)."""
     args = [a if a != "tiny-qwen" or TINY[i - 1] != "--judge-model" else "tiny-judge" for i, a in enumerate(TINY)]
     e = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    import socket
+
+    with socket.socket() as probe:                       # a port that is free now (a fixed one may be taken)
+        probe.bind(("127.0.0.1", 0))
+        port = probe.getsockname()[1]
     p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "4",
-                        "--master-addr", "127.0.0.1", "--master-port", "29741", str(ROOT / "bench.py"), "--gpus", "4",
+                        "--master-addr", "127.0.0.1", "--master-port", str(port), str(ROOT / "bench.py"), "--gpus", "4",
                         "--workload", "D"] + args, capture_output=True, text=True, env=e, timeout=420)
     assert p.returncode == 0, p.stderr[-3000:]
     out = json_line(p)
