@@ -156,8 +156,13 @@ def test_gloo_two_process_collectives_and_replica_bench_path(tmp_path):
     replica-sharded majority-vote flow of bench.py, on two gloo ranks."""
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="2", PYTHONPATH=str(ROOT))
     out = tmp_path / "ok"
+    import socket
+
+    with socket.socket() as probe:                       # a port that is free now (a fixed one may be taken)
+        probe.bind(("127.0.0.1", 0))
+        port = probe.getsockname()[1]
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
-           "--master-addr", "127.0.0.1", "--master-port", "29617", str(ROOT / "tests" / "dist_worker.py"), str(out)]
+           "--master-addr", "127.0.0.1", "--master-port", str(port), str(ROOT / "tests" / "dist_worker.py"), str(out)]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     assert sorted(p.name for p in tmp_path.glob("ok.*")) == ["ok.0", "ok.1"]
