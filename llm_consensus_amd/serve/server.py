@@ -42,7 +42,8 @@ Malformed requests are answered, not crashed on: a bad ``Content-Length`` or a b
 JSON object gets 400, an announced body over ``max_body_bytes`` gets 413 before any of it is read,
 and socket reads and writes give up after ``io_timeout_s`` (half-sent requests, idle kept-alive
 connections, stream readers that stall), so no client can hold a handler thread for ever. The
-listen backlog is 1024.
+listen backlog is 1024; at most ``max_connections`` connections are open at a time (each has a
+handler thread), one more is answered 503 from the accept loop.
 
 At most ``max_pending`` requests are accepted at a time (answered or not yet): one more gets
 429 with a Retry-After header instead of an unbounded wait behind engines that are already full.
@@ -100,7 +101,7 @@ class ConsensusServer:
     def __init__(self, ensemble, host: str = "127.0.0.1", port: int = 8000, max_batch: int = 64,
                  batch_window_ms: float = 5.0, request_timeout_s: float = 600.0, continuous: bool = True,
                  max_pending: int = 4096, api_key: Optional[str] = None, io_timeout_s: float = 60.0,
-                 max_body_bytes: int = 16 << 20) -> None:
+                 max_body_bytes: int = 16 << 20, max_connections: int = 8192) -> None:
         self.ensemble = ensemble
         self.continuous = continuous
         self.max_batch, self.window = max_batch, batch_window_ms / 1e3
@@ -121,6 +122,7 @@ class ConsensusServer:
         self._stop = threading.Event()
         self._draining = threading.Event()       # set by drain(): refuse new requests, finish the admitted ones
         server = self
+        max_connections_ = max_connections
 
         class Handler(BaseHTTPRequestHandler):
             protocol_version = "HTTP/1.1"
@@ -145,6 +147,37 @@ class ConsensusServer:
             # it, and the kernel then drops or resets connections (1 s stalls, ECONNRESET) although
             # the server is idle enough to take them (measured with benchmarks/http_load.py).
             request_queue_size = 1024
+            # One handler thread per open connection: beyond this many, a new connection is told 503
+            # from the accept loop and closed instead of getting a thread of its own.
+            max_connections = max_connections_
+            active = 0
+            active_lock = threading.Lock()
+
+            def process_request(self, request, client_address):
+                with self.active_lock:
+                    over = self.active >= self.max_connections
+                    if not over:
+                        self.active += 1
+                if over:
+                    with server._lock:
+                        server.counters["rejected_total"] += 1
+                    try:
+                        request.settimeout(0.2)
+                        request.sendall(b"HTTP/1.1 503 Service Unavailable\r\nRetry-After: 1\r\nConnection: close\r\n"
+                                        b"Content-Type: application/json\r\nContent-Length: 72\r\n\r\n"
+                                        b'{"error": {"message": "too many open connections", "code": 503}}        ')
+                    except OSError:
+                        pass
+                    self.shutdown_request(request)
+                    return
+                super().process_request(request, client_address)
+
+            def process_request_thread(self, request, client_address):
+                try:
+                    super().process_request_thread(request, client_address)
+                finally:
+                    with self.active_lock:
+                        self.active -= 1
 
             def handle_error(self, request, client_address):
                 # a client that resets its connection is not a server error worth a traceback
@@ -904,6 +937,8 @@ def main(argv: Optional[list] = None) -> int:
                     help="seconds a socket read or write may take (a client that sends half a request, idles on a "
                          "kept-alive connection or stops reading its stream gives its handler thread back)")
     ap.add_argument("--max-body-mb", type=float, default=16.0, help="largest request body accepted (413 beyond)")
+    ap.add_argument("--max-connections", type=int, default=8192,
+                    help="open connections served at a time (each has a handler thread); one more is told 503")
     ap.add_argument("--gpus", type=int, default=None,
                     help="run as this many ranks, one per GPU, started by this command (default: every replica "
                          "of the configured ensemble that the visible GPUs hold)")
@@ -961,7 +996,8 @@ def main(argv: Optional[list] = None) -> int:
         ConsensusServer(ens, args.host, args.port, args.max_batch, args.batch_window_ms,
                         request_timeout_s=args.request_timeout, continuous=not args.batched,
                         max_pending=args.max_pending, api_key=args.api_key, io_timeout_s=args.io_timeout,
-                        max_body_bytes=int(args.max_body_mb * (1 << 20))).serve_forever()
+                        max_body_bytes=int(args.max_body_mb * (1 << 20)),
+                        max_connections=args.max_connections).serve_forever()
     finally:
         if args.distributed:
             ens.close()

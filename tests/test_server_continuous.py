@@ -534,3 +534,35 @@ def test_wrongly_typed_fields_get_400_never_a_dropped_connection():
         assert srv.counters["errors_total"] > 50 and threading.active_count() < 20
     finally:
         srv.shutdown()
+
+
+def test_connections_beyond_the_cap_are_told_503_without_a_thread_of_their_own():
+    import socket
+
+    cfg = config_from_dict({"strategy": "majority_vote", "sampling": {"temperature": 0.0, "max_new_tokens": 2},
+                            "models": {"default": {"preset": "tiny-llama", "seed": 1}},
+                            "members": [{"name": "a", "model": "default"}]})
+    srv = ConsensusServer(build_ensemble(cfg), port=0, max_connections=4, io_timeout_s=5.0).start()
+    idle = []
+    try:
+        for _ in range(4):                              # four connections that just sit there
+            c = socket.create_connection(("127.0.0.1", srv.port), timeout=5)
+            idle.append(c)
+        deadline = time.time() + 5
+        while time.time() < deadline and srv.httpd.active < 4:
+            time.sleep(0.02)
+        with pytest.raises(urllib.error.HTTPError) as e:
+            _post(srv.port, "/v1/completions", {"model": "default", "prompt": "hi", "max_tokens": 2}, timeout=10)
+        assert e.value.code == 503 and e.value.headers.get("Retry-After") == "1"
+        assert "too many" in json.loads(e.value.read())["error"]["message"]
+        for c in idle[:2]:
+            c.close()
+        deadline = time.time() + 10
+        while time.time() < deadline and srv.httpd.active > 2:
+            time.sleep(0.05)
+        code, out = _post(srv.port, "/v1/completions", {"model": "default", "prompt": "hi", "max_tokens": 2})
+        assert code == 200
+    finally:
+        for c in idle:
+            c.close()
+        srv.shutdown()
