@@ -653,11 +653,12 @@ class Engine:
             raise ValueError("empty prompt")
         vocab = self.model.cfg.vocab_size
         for what, arr in (("prompt", ids), ("decision target", decision_ids), ("score target", score_ids)):
-            if arr is not None and len(arr) and (min(arr) < 0 or max(arr) >= vocab):
+            arr = None if arr is None else np.asarray(arr)
+            if arr is not None and arr.size and (int(arr.min()) < 0 or int(arr.max()) >= vocab):
                 # (the kernels clamp such ids rather than read outside the table: the answer would be
                 # wrong without a trace. A tokenizer that does not belong to the model is the usual cause.)
                 raise ValueError(f"{what} token id outside the model's vocabulary of {vocab}: "
-                                 f"{int(min(arr))} .. {int(max(arr))}")
+                                 f"{int(arr.min())} .. {int(arr.max())}")
         if n < 1:
             raise ValueError(f"n = {n}: a request has at least one chain")
         new = p.max_new_tokens if kind == core.RequestKind.Generate else 0
