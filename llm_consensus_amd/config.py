@@ -217,10 +217,17 @@ class ConsensusConfig:
     def templates(self) -> "core.PromptTemplates":
         t = {"persona_last": core.PromptTemplates.persona_last,
              "persona_first": core.PromptTemplates.persona_first}.get(self.prompt_layout, core.PromptTemplates)()
+        needs = {"propose": ("{question}",), "evaluate": ("{question}", "{answer}"), "refine": ("{question}", "{answer}")}
         for attr, path in (("propose", self.prompt_propose), ("evaluate", self.prompt_evaluate),
                            ("refine", self.prompt_refine)):
             if path:
-                setattr(t, attr, Path(path).read_text())
+                text = Path(path).read_text()
+                missing = [ph for ph in needs[attr] if ph not in text]
+                if missing:
+                    # (a template without its placeholders renders, and every member then answers a
+                    # prompt that does not contain the question)
+                    raise ValueError(f"prompt_{attr} = {path}: the template lacks {', '.join(missing)}")
+                setattr(t, attr, text)
         return t
 
     def personas(self) -> List["core.Persona"]:

@@ -441,3 +441,16 @@ def test_server_finds_out_that_its_port_is_taken_before_loading_anything(capsys)
         t0 = time.perf_counter()
         assert server.main(["--device", "cpu", "--port", str(s.getsockname()[1])]) == 2
         assert "cannot listen" in capsys.readouterr().err and time.perf_counter() - t0 < 2.0
+
+
+def test_prompt_template_files_must_keep_their_placeholders(tmp_path):
+    from llm_consensus_amd.config import config_from_dict
+
+    good = tmp_path / "propose.txt"
+    good.write_text("Please answer briefly.\n{question}\n")
+    bad = tmp_path / "evaluate.txt"
+    bad.write_text("Judge this: {question}\n")                   # no {answer}
+    cfg = config_from_dict({"prompt_propose": str(good)})
+    assert "{question}" in cfg.templates().propose and "briefly" in cfg.templates().propose
+    with pytest.raises(ValueError, match=r"prompt_evaluate.*\{answer\}"):
+        config_from_dict({"prompt_evaluate": str(bad)}).templates()
