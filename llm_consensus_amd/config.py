@@ -165,6 +165,8 @@ class ConsensusConfig:
             raise ValueError(f"sampling.max_new_tokens must be an integer >= 1, not {s.max_new_tokens!r}")
         if not _is_int(s.seed):
             raise ValueError(f"sampling.seed must be an integer, not {s.seed!r}")
+        if self.prompt_propose or self.prompt_evaluate or self.prompt_refine:
+            self.templates()          # reads the files and checks their placeholders now, not after the models are loaded
         for spec in self.models.values():
             who = f"model {spec.name!r}"
             for name, lo in (("tp", 1), ("ep", 1), ("kv_blocks", 0), ("max_batch_seqs", 1), ("max_prefill_tokens", 1),

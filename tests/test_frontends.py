@@ -453,4 +453,6 @@ def test_prompt_template_files_must_keep_their_placeholders(tmp_path):
     cfg = config_from_dict({"prompt_propose": str(good)})
     assert "{question}" in cfg.templates().propose and "briefly" in cfg.templates().propose
     with pytest.raises(ValueError, match=r"prompt_evaluate.*\{answer\}"):
-        config_from_dict({"prompt_evaluate": str(bad)}).templates()
+        config_from_dict({"prompt_evaluate": str(bad)})                  # at load time, before any model is built
+    with pytest.raises(OSError):
+        config_from_dict({"prompt_refine": str(tmp_path / "missing.txt")})
