@@ -165,6 +165,10 @@ class ConsensusConfig:
             raise ValueError(f"sampling.max_new_tokens must be an integer >= 1, not {s.max_new_tokens!r}")
         if not _is_int(s.seed):
             raise ValueError(f"sampling.seed must be an integer, not {s.seed!r}")
+        if self.transcript_path:
+            parent = Path(self.transcript_path).resolve().parent
+            if not parent.is_dir() or not os.access(parent, os.W_OK):
+                raise ValueError(f"transcript_path = {self.transcript_path}: {parent} is not a writable directory")
         if self.prompt_propose or self.prompt_evaluate or self.prompt_refine:
             self.templates()          # reads the files and checks their placeholders now, not after the models are loaded
         for spec in self.models.values():
