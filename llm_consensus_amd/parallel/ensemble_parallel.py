@@ -246,7 +246,7 @@ class ShardedBackend(Backend):
                     rec.update(kind="gen", ids=[list(map(int, t)) for t in v.token_ids],
                                lp=[float(x) for x in v.cum_logprobs],
                                dec=[[float(x) for x in d] for d in v.decision_logprobs] if v.decision_logprobs else None,
-                               pt=int(v.prompt_tokens), ct=int(v.cached_tokens))
+                               pt=int(v.prompt_tokens), ct=int(v.cached_tokens), fr=list(v.finish_reasons or ()))
                 elif e["gen"] is not None:
                     rec.update(kind="text", texts=list(v.texts),
                                dec=[[float(x) for x in d] for d in v.decision_logprobs] if v.decision_logprobs else None)
@@ -271,7 +271,8 @@ class ShardedBackend(Backend):
             return self._complete(e, "err", rec["msg"], None)
         if kind == "gen":
             v = GenResult(texts=[self._text_of(t) for t in rec["ids"]], token_ids=rec["ids"], cum_logprobs=rec["lp"],
-                          decision_logprobs=rec["dec"], prompt_tokens=rec["pt"], cached_tokens=rec["ct"])
+                          decision_logprobs=rec["dec"], prompt_tokens=rec["pt"], cached_tokens=rec["ct"],
+                          finish_reasons=list(rec.get("fr") or ()))
         elif kind == "text":
             v = GenResult(texts=rec["texts"], decision_logprobs=rec["dec"])
         else:
