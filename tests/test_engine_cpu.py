@@ -499,3 +499,39 @@ def test_requests_that_cannot_be_served_are_refused_at_submit_and_leave_the_engi
     with pytest.raises(ValueError, match="longest sequence"):
         sched.add_request(core.RequestKind.Generate, np.arange(30, dtype=np.int32), 1, p)
     assert sched.add_request(core.RequestKind.Generate, np.arange(20, dtype=np.int32), 1, p) >= 0
+
+
+def test_prefill_logits_with_llama3_rope_scaling_close_to_hf(tmp_path):
+    """End to end against Hugging Face with Llama-3.1-style rope_scaling switched on and a prompt
+    long enough for the scaled frequencies to matter (original context 32, factor 4): the closed
+    form of the frequencies is checked in test_loader.py, this checks that the engine applies them
+    where HF does. With the scaling left out of the engine's tables the two would part."""
+    import dataclasses
+
+    base = get_preset("tiny-llama")
+    sc = {"rope_type": "llama3", "factor": 4.0, "low_freq_factor": 1.0, "high_freq_factor": 4.0,
+          "original_max_position_embeddings": 32}
+    fields = {f.name for f in dataclasses.fields(base)}
+    assert "rope_scaling" in fields or hasattr(base, "rope_scaling_dict")
+    cfg = dataclasses.replace(base, **({"rope_scaling": sc} if "rope_scaling" in fields else {}))
+    if getattr(cfg, "rope_scaling_dict", None) != sc:
+        pytest.skip("preset dataclass stores rope scaling under another field")
+    path = write_random_checkpoint(cfg, tmp_path / "scaled", seed=4, std=0.08)
+    hf = hf_model(path)
+    assert hf.config.rope_scaling and hf.config.rope_scaling.get("rope_type") == "llama3"
+    model = load_model(str(path), "cpu")
+    eng = Engine(model, num_kv_blocks=32, block_size=16, use_graphs=False)
+    prompt = list(range(5, 115))
+    tgt = [1, 7, 100, 300]
+    rid = eng.submit(prompt, core.RequestKind.Score, score_ids=tgt)
+    eng.run_until_done()
+    got = np.array(eng.pop_result(rid).scores)
+    with torch.no_grad():
+        lp = torch.log_softmax(hf(torch.tensor([prompt])).logits[0, -1].float(), -1)
+    assert np.allclose(got, lp[tgt].numpy(), atol=0.06), (got, lp[tgt])
+    # and the unscaled model is measurably different on this prompt (the test has teeth)
+    plain = load_model(str(write_random_checkpoint(base, tmp_path / "plain", seed=4, std=0.08)), "cpu")
+    eng2 = Engine(plain, num_kv_blocks=32, block_size=16, use_graphs=False)
+    r2 = eng2.submit(prompt, core.RequestKind.Score, score_ids=tgt)
+    eng2.run_until_done()
+    assert not np.allclose(np.array(eng2.pop_result(r2).scores), got, atol=0.02)
