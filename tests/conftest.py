@@ -10,6 +10,13 @@ if str(ROOT) not in sys.path:
 
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
+if os.environ.get("PYTEST_XDIST_WORKER"):
+    # pytest -n N: every worker would start a full-size torch thread pool; with a handful of workers
+    # on a small machine the CPU engine tests then crawl (40 minutes for what takes one in a single
+    # process). One compute thread per worker keeps the workers out of each other's way.
+    os.environ.setdefault("OMP_NUM_THREADS", "1")
+    os.environ.setdefault("MKL_NUM_THREADS", "1")
+
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
