@@ -1,5 +1,6 @@
 """Continuous protocol driver (SessionPool) against the wave driver, and late admission."""
 import numpy as np
+import pytest
 
 from llm_consensus_amd._native import core
 from llm_consensus_amd.consensus.backend import GenParams, ScriptedBackend
@@ -72,3 +73,59 @@ def test_sessions_join_while_others_are_in_flight_and_two_engines_overlap():
     assert all(not be._pending for be in bes)
     st = bes[0].engine.stats()
     assert st["requests.finished"] >= 3
+
+
+@pytest.mark.parametrize("strategy", ["reference_protocol", "majority_vote", "self_consistency", "judge_logprob",
+                                      "embedding_medoid"])
+@pytest.mark.parametrize("seed", range(2))
+def test_pools_with_random_cancellations_answer_the_rest_and_leave_nothing_behind(strategy, seed):
+    """Every kind of pool over real (CPU) engines: questions join at random pumps, some are
+    cancelled at random moments (first or second phase, waiting or decoding). A cancelled ticket
+    produces no result, every other ticket exactly one, and at the end no backend holds a pending
+    request, a leftover or a KV block."""
+    import numpy as np
+    import torch
+
+    from llm_consensus_amd.app import build_ensemble
+    from llm_consensus_amd.config import config_from_dict
+    from llm_consensus_amd.consensus.protocol import SessionPool
+
+    roles = {"judge_logprob": ["member", "member", "judge"], "embedding_medoid": ["member", "member", "embedder"]}
+    members = [{"name": f"m{i}", "model": "a" if i % 2 == 0 else "b", "role": r}
+               for i, r in enumerate(roles.get(strategy, ["member"] * 3))]
+    cfg = config_from_dict({"strategy": strategy, "decision_mode": "logprob", "k_chains": 3, "seed": 5,
+                            "sampling": {"temperature": 0.7, "max_new_tokens": 5},
+                            "models": {"a": {"preset": "tiny-llama", "seed": 1, "kv_blocks": 256},
+                                       "b": {"preset": "tiny-qwen", "seed": 2, "kv_blocks": 256}},
+                            "members": members})
+    ens = build_ensemble(cfg, torch.device("cpu"))
+    pool = SessionPool(ens.strategy) if strategy == "reference_protocol" else ens.strategy.pool()
+    rng = np.random.default_rng(11 + seed)
+    n_q = 14
+    arrive = sorted(int(x) for x in rng.integers(0, 40, size=n_q))
+    tickets, cancelled, results = [], set(), {}
+    for pump in range(4000):
+        while arrive and arrive[0] <= pump:
+            arrive.pop(0)
+            tickets.append(pool.submit(f"question number {len(tickets)}: which option, A, B, C or D?"))
+        live = [t for t in tickets if t not in results and t not in cancelled]
+        if live and rng.integers(6) == 0:
+            t = live[int(rng.integers(len(live)))]
+            if pool.cancel(t):
+                cancelled.add(t)
+        for t, res in pool.pump():
+            assert t not in results and t not in cancelled
+            results[t] = res
+        if not arrive and not pool.active:
+            break
+    assert len(tickets) == n_q and cancelled and set(results) | cancelled == set(tickets)
+    assert not pool.cancel(tickets[0]) or tickets[0] not in results          # a finished ticket is not cancellable
+    # cancelled member calls leave the engines at their next step
+    for _ in range(200):
+        if not any(b.has_leftovers() or b.engines() for b in ens.backends.values()):
+            break
+        pool.stepper.step()
+    for name, b in ens.backends.items():
+        st = b.engine.stats()
+        assert not b._pending and not b.has_leftovers() and st["sched.running"] == 0, (name, st)
+        assert st["kv.blocks_free"] + st["kv.blocks_cached"] == st["kv.blocks_total"], (name, st)
