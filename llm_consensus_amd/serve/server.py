@@ -622,6 +622,20 @@ class ConsensusServer:
                 "data": [{"id": i, "object": "model", "created": now, "owned_by": "llm_consensus_amd"} for i in ids]}
 
     def _metrics(self) -> str:
+        # Built at most twice a second (scrapers ask every few seconds): collecting every engine's
+        # statistics holds the interpreter lock, which the thread that drives the engines needs too.
+        # This bounds the cost of the collection only: every request, however cheap, costs handler
+        # time under the same lock, so a flood of them still slows serving (hundreds of GETs per
+        # second halve a CPU-backed run); rate limiting belongs to the proxy in front.
+        now = time.perf_counter()
+        cached = getattr(self, "_metrics_cache", None)
+        if cached is not None and now - cached[0] < 0.5:
+            return cached[1]
+        text = self._metrics_text()
+        self._metrics_cache = (now, text)
+        return text
+
+    def _metrics_text(self) -> str:
         lines = []
         with self._lock:
             for k, v in self.counters.items():
